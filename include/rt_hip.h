@@ -1,0 +1,123 @@
+/*
+ * rt_hip.h -- C-ABI of the MI355X path-tracing library (librt_hip.so).
+ *
+ * This is the boundary a host in any language binds to (plain pointers and sizes, no HIP or torch
+ * types).  It replaces the reference's Rust `CudaWorld` device layer
+ * (gpu-implementation/src/ray_tracing.rs:73-211: cudarc context, NVRTC module, kernel launch, D2H copy)
+ * with hipModuleLoadData / hipModuleLaunchKernel / hipMemcpy on a gfx950 code object that is built
+ * ahead of time and embedded in the library.  Every entry point cites the reference interface it stands for.
+ *
+ * Conventions: every function returns 0 on success or a non-zero code (a hipError_t value, or
+ * RT_ERR_* below); the message is available from rt_last_error().  Nothing aborts or throws across
+ * the boundary.  Calls on one context are blocking and must not overlap; use one context per GPU
+ * (contexts may be driven from different host threads).  The caller owns every host buffer; the
+ * context owns its device buffers and re-allocates them when sizes change.
+ */
+#ifndef RT_HIP_H
+#define RT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include "rt_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_ERR_INVALID   10001  /* bad argument */
+#define RT_ERR_NO_MODULE 10002  /* no code object loaded */
+#define RT_ERR_NO_SCENE  10003  /* rt_upload_scene not called yet */
+#define RT_ERR_IO        10004  /* file output failed */
+
+typedef struct rt_ctx rt_ctx;
+
+/* Creates a context on GPU `device`, its stream, and loads the embedded code object.
+ * Stands for CudaWorld::new (ray_tracing.rs:106-127); failures are returned, not panics. */
+int rt_create(int device, rt_ctx **out);
+
+/* Frees device buffers, module and stream (the reference relies on Drop). */
+void rt_destroy(rt_ctx *ctx);
+
+/* Last error message of this context (of the failed rt_create when ctx is NULL).
+ * Stands for the error strings the reference pushes to its GUI (ray_tracing.rs:154-158, 202-204). */
+const char *rt_last_error(const rt_ctx *ctx);
+
+/* Replaces the kernels by another gfx950 code object image (hipModuleLoadData), or reloads the
+ * embedded one when image == NULL.  Stands for CudaWorld::compile_ptx (ray_tracing.rs:129-161);
+ * the reference compiles at run time with NVRTC, here the object is built by hipcc --genco. */
+int rt_load_module(rt_ctx *ctx, const void *image, size_t size);
+
+/* Uploads the sphere list: AoS host spheres -> device float4 arrays (geometry {c, r*r}; surface
+ * {radius, fuzz|ior, material}; albedo).  Stands for the scene the reference builds inside its kernel
+ * (gpu-implementation/src/cuda/ray.cu:94-106) and for the `world: &[T]` argument of Camera::render
+ * (cpu-implementation/src/lib.rs:221). */
+int rt_upload_scene(rt_ctx *ctx, const RtSphere *spheres, uint32_t n);
+
+/* Renders image rows [row0, row0+rows) and copies them to host buffers (blocking).
+ *   rgba_out   rows*W*4 bytes RGBA8, row-major                       (required)
+ *   linear_out rows*W*4 floats: mean radiance before gamma, r,g,b,1  (may be NULL)
+ *   hit_out    rows*W int32: closest sphere of each pixel-centre ray, -1 = none (may be NULL)
+ *   rays_out   number of ray segments traced (may be NULL)
+ * `cam` must be initialised (rt_camera_initialize or rt_camera_new_cpu).
+ * Stands for CudaWorld::render (ray_tracing.rs:163-210) and Camera::render (lib.rs:221-242). */
+int rt_render_rows(rt_ctx *ctx, const RtCamera *cam, const RtParams *params, uint32_t row0, uint32_t rows,
+                   uint8_t *rgba_out, float *linear_out, int32_t *hit_out, uint64_t *rays_out);
+
+/* Renders an interleaved set of row tiles into caller-owned DEVICE memory (no host copy): tile k
+ * (k = 0..n_tiles-1) covers image rows (first_tile + k*tile_stride)*tile_rows ... +tile_rows-1 and is
+ * written at local rows k*tile_rows... of the compact output.  Rows past the image end are skipped.
+ *   d_rgba   device pointer, n_tiles*tile_rows*W*4 bytes             (required)
+ *   d_linear device pointer, n_tiles*tile_rows*W*4 floats            (may be NULL)
+ * Blocking: returns after the kernel has finished.  Used to split one image over the GPUs of a node
+ * (rank r of n renders tiles r, r+n, ...).  No counterpart in the reference, which is single-GPU
+ * (ray_tracing.rs:107); it is the same launch as rt_render_rows with a different row mapping. */
+int rt_render_tiles_device(rt_ctx *ctx, const RtCamera *cam, const RtParams *params, uint32_t tile_rows,
+                           uint32_t first_tile, uint32_t tile_stride, uint32_t n_tiles,
+                           void *d_rgba, void *d_linear, uint64_t *rays_out);
+
+/* Closest-hit index map only (no shading).  The reference has no such output; it is the integer
+ * result of hit_world (ray.cu:1-18) / `[T]::hit` (lib.rs:127-135) for the first segment. */
+int rt_primary_hits(rt_ctx *ctx, const RtCamera *cam, const RtParams *params, uint32_t row0, uint32_t rows,
+                    int32_t *hit_out);
+
+/* RNG debug views `show_random` / `random_norm` of the reference kernel (ray.cu:114-118):
+ * per pixel three uniform values (norm = 0) or one random unit vector (norm != 0) as RGBA8. */
+int rt_show_random(rt_ctx *ctx, uint32_t width, uint32_t height, uint64_t seed, int norm, uint8_t *rgba_out);
+
+/* Milliseconds the last render kernel took on the GPU (hipEvent pair around the launch). */
+float rt_last_kernel_ms(const rt_ctx *ctx);
+
+/* Name and compute-unit count of the context's GPU. */
+int rt_device_info(const rt_ctx *ctx, char *name, size_t name_size, int *compute_units, int *clock_khz);
+
+/* ---- host-side helpers (no GPU needed) ---- */
+
+/* camera::Camera::new(aspect_ratio, image_width) + initialize() with the reference's defaults
+ * (vfov 90, lookfrom (-2,2,1), lookat (0,0,-1), vup (0,1,0); ray_tracing.rs:275-298). */
+int rt_camera_new(float aspect_ratio, uint32_t image_width, RtCamera *out);
+/* camera::Camera::initialize (ray_tracing.rs:300-336): recomputes the derived fields in f32. */
+int rt_camera_initialize(RtCamera *cam);
+/* Camera::new(aspect_ratio, image_width, _) of the CPU crate (lib.rs:148-183): fixed pinhole at the
+ * origin, computed in f64 and rounded into the f32 block. */
+int rt_camera_new_cpu(double aspect_ratio, uint32_t image_width, RtCamera *out);
+
+/* Scene builders.  Each writes up to `cap` spheres and returns the scene's sphere count (call with
+ * cap = 0 to size the buffer). */
+/* The two spheres of cpu-implementation/src/main.rs:26-28 (Lambertian, albedo 0.5). */
+uint32_t rt_scene_cpu_default(RtSphere *out, uint32_t cap);
+/* The nine spheres of gpu-implementation/src/cuda/ray.cu:97-106. */
+uint32_t rt_scene_gpu_default(RtSphere *out, uint32_t cap);
+/* "Ray Tracing in One Weekend" final scene (ground + up to 22x22 small spheres + 3 large ones). */
+uint32_t rt_scene_book1_final(uint64_t seed, RtSphere *out, uint32_t cap);
+/* Ground + side x side jittered grid of small spheres (side = 128 gives 16,385 spheres). */
+uint32_t rt_scene_grid(uint64_t seed, uint32_t side, RtSphere *out, uint32_t cap);
+/* Two facing mirrors (ray.cu:103-104) with `n_small` metal/glass spheres between them. */
+uint32_t rt_scene_mirror_hall(uint64_t seed, uint32_t n_small, RtSphere *out, uint32_t cap);
+
+/* Binary PPM (P6) of the RGB channels of an RGBA8 frame. */
+int rt_write_ppm(const char *path, const uint8_t *rgba, uint32_t width, uint32_t height);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_HIP_H */

@@ -1,0 +1,34 @@
+// rt_device.h -- kernel-side layout shared by the gfx950 code object (rt_kernels.hip) and the
+// host launcher (rt_hip.cpp).  Not part of the public interface.
+#ifndef RT_DEVICE_H
+#define RT_DEVICE_H
+
+#include <stdint.h>
+#include "../../include/rt_types.h"
+
+// Second kernel argument, by value (the camera block is the first by-value argument, as in the
+// reference's `render(rng_state, frame, Camera cam, GuiState gui)`, ray.cu:92).
+typedef struct RtLaunch {
+    uint32_t n_spheres;        // spheres in the scene
+    uint32_t n_padded;         // n_spheres rounded up to RT_SCAN_UNROLL (padding never hits)
+    uint32_t samples_per_pixel;
+    uint32_t sample2_per_pixel;
+    uint32_t max_depth;
+    uint32_t flags;
+    uint32_t seed_lo, seed_hi;
+    float    t_min, t_max;
+    uint32_t width, height;    // full image
+    uint32_t row_base;         // global row of local row 0
+    uint32_t rows_local;       // rows this launch renders (compact output buffer height)
+    uint32_t tile_rows;        // local rows per row tile
+    uint32_t tile_stride_rows; // global row distance between consecutive row tiles of this launch
+    uint32_t tiles_x;          // 8x8 wave tiles per image row = ceil(width / 8)
+    uint32_t n_wave_tiles;     // tiles_x * ceil(rows_local / 8)
+} RtLaunch;
+
+#define RT_SCAN_UNROLL 8u
+// Spheres staged in LDS at a time: 4096 x 16 B = 64 KiB.  Scenes up to this size are staged once per
+// workgroup; larger ones are streamed through the same buffer tile by tile.
+#define RT_TILE_SPHERES 4096u
+
+#endif

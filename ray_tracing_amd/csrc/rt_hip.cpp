@@ -1,0 +1,363 @@
+// rt_hip.cpp -- device half of the C-ABI declared in include/rt_hip.h: a thin layer over
+// hipModuleLoadData / hipModuleLaunchKernel / hipMalloc / hipMemcpy driving the gfx950 code object
+// built from rt_kernels.hip (embedded below with .incbin).  It takes the place of the reference's
+// cudarc-based CudaWorld (gpu-implementation/src/ray_tracing.rs:73-211).  Host C++ only.
+#include <hip/hip_runtime_api.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/rt_hip.h"
+#include "rt_device.h"
+
+// The code object produced by `hipcc --offload-arch=gfx950 --genco rt_kernels.hip`.
+__asm__(
+    ".section .rodata\n"
+    ".balign 4096\n"
+    ".global rt_embedded_hsaco\n"
+    "rt_embedded_hsaco:\n"
+    ".incbin \"rt_kernels.hsaco\"\n"
+    ".global rt_embedded_hsaco_end\n"
+    "rt_embedded_hsaco_end:\n"
+    ".byte 0\n"
+    ".previous\n");
+extern "C" const unsigned char rt_embedded_hsaco[];
+extern "C" const unsigned char rt_embedded_hsaco_end[];
+
+struct rt_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipModule_t module = nullptr;
+    hipFunction_t f_render = nullptr, f_render_stream = nullptr, f_hits = nullptr, f_random = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    void *d_geom = nullptr, *d_surf = nullptr, *d_albedo = nullptr;
+    uint32_t n_spheres = 0, n_padded = 0;
+    bool have_scene = false;
+    void *d_rgba = nullptr, *d_linear = nullptr, *d_hits = nullptr, *d_counter = nullptr;
+    size_t cap_rgba = 0, cap_linear = 0, cap_hits = 0;
+    float last_ms = 0.0f;
+    int compute_units = 0, clock_khz = 0;
+    char name[600] = {0};
+    std::string err;
+};
+
+static std::string g_create_error;
+
+namespace {
+
+int fail(rt_ctx* c, int code, const std::string& msg) {
+    if (c) c->err = msg; else g_create_error = msg;
+    return code;
+}
+
+int hip_fail(rt_ctx* c, hipError_t e, const char* what) {
+    std::string m = std::string(what) + ": " + hipGetErrorName(e) + " (" + hipGetErrorString(e) + ")";
+    return fail(c, (int)e, m);
+}
+
+#define RT_HIP(ctx, call)                                         \
+    do {                                                          \
+        hipError_t e__ = (call);                                  \
+        if (e__ != hipSuccess) return hip_fail((ctx), e__, #call); \
+    } while (0)
+
+int ensure(rt_ctx* c, void** p, size_t* cap, size_t bytes) {
+    if (*cap >= bytes && *p) return 0;
+    if (*p) { RT_HIP(c, hipFree(*p)); *p = nullptr; *cap = 0; }
+    RT_HIP(c, hipMalloc(p, bytes));
+    *cap = bytes;
+    return 0;
+}
+
+int load_image(rt_ctx* c, const void* image) {
+    hipModule_t m = nullptr;
+    RT_HIP(c, hipModuleLoadData(&m, image));
+    hipFunction_t fr, fs, fh, fx;
+    hipError_t e;
+    if ((e = hipModuleGetFunction(&fr, m, "rt_render")) != hipSuccess ||
+        (e = hipModuleGetFunction(&fs, m, "rt_render_stream")) != hipSuccess ||
+        (e = hipModuleGetFunction(&fh, m, "rt_primary_hits")) != hipSuccess ||
+        (e = hipModuleGetFunction(&fx, m, "rt_show_random")) != hipSuccess) {
+        (void)hipModuleUnload(m);
+        return hip_fail(c, e, "hipModuleGetFunction");
+    }
+    if (c->module) (void)hipModuleUnload(c->module);
+    c->module = m;
+    c->f_render = fr; c->f_render_stream = fs; c->f_hits = fh; c->f_random = fx;
+    return 0;
+}
+
+int check_common(rt_ctx* c, const RtCamera* cam, const RtParams* p) {
+    if (!c) return RT_ERR_INVALID;
+    if (!cam || !p) return fail(c, RT_ERR_INVALID, "camera or params is NULL");
+    if (!c->module) return fail(c, RT_ERR_NO_MODULE, "no code object loaded");
+    if (!c->have_scene) return fail(c, RT_ERR_NO_SCENE, "rt_upload_scene has not been called");
+    if (cam->image_width == 0 || cam->image_height == 0) return fail(c, RT_ERR_INVALID, "camera not initialised (zero image size)");
+    if ((uint64_t)cam->image_width * cam->image_height >= (1ull << 31)) return fail(c, RT_ERR_INVALID, "image has 2^31 pixels or more");
+    if (!(p->t_min >= 0.0f)) return fail(c, RT_ERR_INVALID, "t_min must be >= 0");
+    if (!(p->t_max > p->t_min)) return fail(c, RT_ERR_INVALID, "t_max must be > t_min");
+    if (p->block_dim != 0 && (p->block_dim % 64 != 0 || p->block_dim < 64 || p->block_dim > 1024))
+        return fail(c, RT_ERR_INVALID, "block_dim must be a multiple of 64 in 64..1024");
+    return 0;
+}
+
+int check_render(rt_ctx* c, const RtParams* p) {
+    if (p->samples_per_pixel == 0) return fail(c, RT_ERR_INVALID, "samples_per_pixel must be >= 1");
+    if (p->flags & RT_FLAG_SAMPLER_GRID) {
+        if (p->sample2_per_pixel == 0 || (uint64_t)p->sample2_per_pixel * p->sample2_per_pixel != p->samples_per_pixel)
+            return fail(c, RT_ERR_INVALID, "grid sampler needs samples_per_pixel == sample2_per_pixel^2");
+    }
+    return 0;
+}
+
+RtLaunch make_launch(const rt_ctx* c, const RtCamera* cam, const RtParams* p, uint32_t row_base,
+                     uint32_t rows_local, uint32_t tile_rows, uint32_t tile_stride_rows) {
+    RtLaunch L;
+    std::memset(&L, 0, sizeof L);
+    L.n_spheres = c->n_spheres;
+    L.n_padded = c->n_padded;
+    L.samples_per_pixel = p->samples_per_pixel;
+    L.sample2_per_pixel = p->sample2_per_pixel ? p->sample2_per_pixel : 1u;
+    L.max_depth = p->max_depth;
+    L.flags = p->flags;
+    L.seed_lo = (uint32_t)(p->seed & 0xffffffffu);
+    L.seed_hi = (uint32_t)(p->seed >> 32);
+    L.t_min = p->t_min;
+    L.t_max = p->t_max;
+    L.width = cam->image_width;
+    L.height = cam->image_height;
+    L.row_base = row_base;
+    L.rows_local = rows_local;
+    L.tile_rows = tile_rows;
+    L.tile_stride_rows = tile_stride_rows;
+    L.tiles_x = (cam->image_width + 7u) / 8u;
+    L.n_wave_tiles = L.tiles_x * ((rows_local + 7u) / 8u);
+    return L;
+}
+
+void launch_geometry(const RtParams* p, const RtLaunch& L, unsigned* grid, unsigned* block) {
+    *block = p->block_dim ? p->block_dim : 256u;
+    unsigned waves = *block / 64u;
+    *grid = (L.n_wave_tiles + waves - 1u) / waves;
+}
+
+size_t lds_bytes(const rt_ctx* c) {
+    uint32_t n = c->n_padded < RT_TILE_SPHERES ? c->n_padded : RT_TILE_SPHERES;
+    return (size_t)n * 16u;
+}
+
+// One render launch into device buffers; blocking; fills last_ms and (optionally) the segment count.
+int launch_render(rt_ctx* c, const RtCamera* cam, const RtParams* p, RtLaunch L, void* d_rgba, void* d_linear,
+                  uint64_t* rays_out) {
+    unsigned grid, block;
+    launch_geometry(p, L, &grid, &block);
+    void* d_count = rays_out ? c->d_counter : nullptr;
+    if (rays_out) RT_HIP(c, hipMemsetAsync(c->d_counter, 0, 8, c->stream));
+    RtCamera cam_copy = *cam;
+    void* args[] = {&c->d_geom, &c->d_surf, &c->d_albedo, &d_rgba, &d_linear, &d_count, &cam_copy, &L};
+    hipFunction_t f = (c->n_padded <= RT_TILE_SPHERES) ? c->f_render : c->f_render_stream;
+    RT_HIP(c, hipEventRecord(c->ev0, c->stream));
+    if (grid > 0)
+        RT_HIP(c, hipModuleLaunchKernel(f, grid, 1, 1, block, 1, 1, (unsigned)lds_bytes(c), c->stream, args, nullptr));
+    RT_HIP(c, hipEventRecord(c->ev1, c->stream));
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    RT_HIP(c, hipEventElapsedTime(&c->last_ms, c->ev0, c->ev1));
+    if (rays_out) RT_HIP(c, hipMemcpy(rays_out, c->d_counter, 8, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int launch_hits(rt_ctx* c, const RtCamera* cam, const RtParams* p, RtLaunch L, void* d_hits) {
+    unsigned grid, block;
+    launch_geometry(p, L, &grid, &block);
+    RtCamera cam_copy = *cam;
+    void* args[] = {&c->d_geom, &d_hits, &cam_copy, &L};
+    if (grid > 0)
+        RT_HIP(c, hipModuleLaunchKernel(c->f_hits, grid, 1, 1, block, 1, 1, (unsigned)lds_bytes(c), c->stream, args, nullptr));
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* rt_last_error(const rt_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int rt_create(int device, rt_ctx** out) {
+    if (!out) return RT_ERR_INVALID;
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess) return hip_fail(nullptr, e, "hipGetDeviceCount");
+    if (device < 0 || device >= count) return fail(nullptr, RT_ERR_INVALID, "no such GPU device");
+    rt_ctx* c = new rt_ctx();
+    c->device = device;
+    int rc = 0;
+    auto bail = [&](int code) { g_create_error = c->err; rt_destroy(c); return code; };
+    if ((e = hipSetDevice(device)) != hipSuccess) return bail(hip_fail(c, e, "hipSetDevice"));
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return bail(hip_fail(c, e, "hipGetDeviceProperties"));
+    std::snprintf(c->name, sizeof c->name, "%s (%s)", prop.name, prop.gcnArchName);
+    c->compute_units = prop.multiProcessorCount;
+    c->clock_khz = prop.clockRate;
+    if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail(hip_fail(c, e, "hipStreamCreate"));
+    if ((e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess)
+        return bail(hip_fail(c, e, "hipEventCreate"));
+    if ((e = hipMalloc(&c->d_counter, 8)) != hipSuccess) return bail(hip_fail(c, e, "hipMalloc"));
+    if ((rc = load_image(c, rt_embedded_hsaco)) != 0) return bail(rc);
+    *out = c;
+    return 0;
+}
+
+void rt_destroy(rt_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    void* bufs[] = {c->d_geom, c->d_surf, c->d_albedo, c->d_rgba, c->d_linear, c->d_hits, c->d_counter};
+    for (void* b : bufs) if (b) (void)hipFree(b);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->module) (void)hipModuleUnload(c->module);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int rt_load_module(rt_ctx* c, const void* image, size_t size) {
+    if (!c) return RT_ERR_INVALID;
+    RT_HIP(c, hipSetDevice(c->device));
+    if (!image) return load_image(c, rt_embedded_hsaco);
+    if (size < 64) return fail(c, RT_ERR_INVALID, "code object image too small");
+    return load_image(c, image);
+}
+
+int rt_upload_scene(rt_ctx* c, const RtSphere* spheres, uint32_t n) {
+    if (!c) return RT_ERR_INVALID;
+    if (n && !spheres) return fail(c, RT_ERR_INVALID, "spheres is NULL");
+    if (n > (1u << 24)) return fail(c, RT_ERR_INVALID, "more than 2^24 spheres");
+    RT_HIP(c, hipSetDevice(c->device));
+    uint32_t n_padded = ((n + RT_SCAN_UNROLL - 1u) / RT_SCAN_UNROLL) * RT_SCAN_UNROLL;
+    if (n_padded == 0) n_padded = RT_SCAN_UNROLL;
+    std::vector<float> geom((size_t)n_padded * 4), surf((size_t)n_padded * 4), alb((size_t)n_padded * 4);
+    for (uint32_t i = 0; i < n_padded; i++) {
+        float* g = &geom[4 * (size_t)i];
+        float* s = &surf[4 * (size_t)i];
+        float* a = &alb[4 * (size_t)i];
+        if (i < n) {
+            const RtSphere& sp = spheres[i];
+            if (sp.material < RT_MAT_DIFFUSE || sp.material > RT_MAT_DIELECTRIC)
+                return fail(c, RT_ERR_INVALID, "unknown material tag in sphere " + std::to_string(i));
+            g[0] = sp.center[0]; g[1] = sp.center[1]; g[2] = sp.center[2];
+            g[3] = sp.radius * sp.radius;            // radius*radius, library.cu:203 / lib.rs:101
+            s[0] = sp.radius;
+            float param = sp.param;
+            if (sp.material == RT_MAT_REFLECT) param = param < 1.0f ? param : 1.0f;   // library.cu:144
+            s[1] = param;
+            std::memcpy(&s[2], &sp.material, 4);
+            s[3] = 0.0f;
+            a[0] = sp.albedo[0]; a[1] = sp.albedo[1]; a[2] = sp.albedo[2]; a[3] = 0.0f;
+        } else {
+            // padding up to the scan's unroll factor: r*r = -inf makes the discriminant -inf, never a hit
+            g[0] = g[1] = g[2] = 0.0f; g[3] = -INFINITY;
+            s[0] = 1.0f; s[1] = 0.0f; s[2] = 0.0f; s[3] = 0.0f;
+            a[0] = a[1] = a[2] = a[3] = 0.0f;
+        }
+    }
+    size_t bytes = (size_t)n_padded * 16u;
+    if (c->d_geom) { RT_HIP(c, hipFree(c->d_geom)); c->d_geom = nullptr; }
+    if (c->d_surf) { RT_HIP(c, hipFree(c->d_surf)); c->d_surf = nullptr; }
+    if (c->d_albedo) { RT_HIP(c, hipFree(c->d_albedo)); c->d_albedo = nullptr; }
+    c->have_scene = false;
+    RT_HIP(c, hipMalloc(&c->d_geom, bytes));
+    RT_HIP(c, hipMalloc(&c->d_surf, bytes));
+    RT_HIP(c, hipMalloc(&c->d_albedo, bytes));
+    RT_HIP(c, hipMemcpy(c->d_geom, geom.data(), bytes, hipMemcpyHostToDevice));
+    RT_HIP(c, hipMemcpy(c->d_surf, surf.data(), bytes, hipMemcpyHostToDevice));
+    RT_HIP(c, hipMemcpy(c->d_albedo, alb.data(), bytes, hipMemcpyHostToDevice));
+    c->n_spheres = n;
+    c->n_padded = n_padded;
+    c->have_scene = true;
+    return 0;
+}
+
+int rt_render_rows(rt_ctx* c, const RtCamera* cam, const RtParams* p, uint32_t row0, uint32_t rows,
+                   uint8_t* rgba_out, float* linear_out, int32_t* hit_out, uint64_t* rays_out) {
+    int rc = check_common(c, cam, p);
+    if (rc) return rc;
+    if ((rc = check_render(c, p))) return rc;
+    if (!rgba_out) return fail(c, RT_ERR_INVALID, "rgba_out is NULL");
+    if (rows == 0 || row0 >= cam->image_height || rows > cam->image_height - row0)
+        return fail(c, RT_ERR_INVALID, "row range outside the image");
+    RT_HIP(c, hipSetDevice(c->device));
+    size_t px = (size_t)rows * cam->image_width;
+    if ((rc = ensure(c, &c->d_rgba, &c->cap_rgba, px * 4))) return rc;
+    if (linear_out && (rc = ensure(c, &c->d_linear, &c->cap_linear, px * 16))) return rc;
+    RtLaunch L = make_launch(c, cam, p, row0, rows, rows, rows);
+    if ((rc = launch_render(c, cam, p, L, c->d_rgba, linear_out ? c->d_linear : nullptr, rays_out))) return rc;
+    RT_HIP(c, hipMemcpy(rgba_out, c->d_rgba, px * 4, hipMemcpyDeviceToHost));      // memcpy_dtoh, ray_tracing.rs:206-208
+    if (linear_out) RT_HIP(c, hipMemcpy(linear_out, c->d_linear, px * 16, hipMemcpyDeviceToHost));
+    if (hit_out) return rt_primary_hits(c, cam, p, row0, rows, hit_out);
+    return 0;
+}
+
+int rt_render_tiles_device(rt_ctx* c, const RtCamera* cam, const RtParams* p, uint32_t tile_rows,
+                           uint32_t first_tile, uint32_t tile_stride, uint32_t n_tiles,
+                           void* d_rgba, void* d_linear, uint64_t* rays_out) {
+    int rc = check_common(c, cam, p);
+    if (rc) return rc;
+    if ((rc = check_render(c, p))) return rc;
+    if (!d_rgba) return fail(c, RT_ERR_INVALID, "d_rgba is NULL");
+    if (tile_rows == 0 || tile_rows % 8u != 0) return fail(c, RT_ERR_INVALID, "tile_rows must be a positive multiple of 8");
+    if (tile_stride == 0) return fail(c, RT_ERR_INVALID, "tile_stride must be >= 1");
+    if ((uint64_t)n_tiles * tile_rows >= (1ull << 31)) return fail(c, RT_ERR_INVALID, "too many tile rows");
+    RT_HIP(c, hipSetDevice(c->device));
+    if (n_tiles == 0) { if (rays_out) *rays_out = 0; c->last_ms = 0.0f; return 0; }
+    RtLaunch L = make_launch(c, cam, p, first_tile * tile_rows, n_tiles * tile_rows, tile_rows, tile_stride * tile_rows);
+    return launch_render(c, cam, p, L, d_rgba, d_linear, rays_out);
+}
+
+int rt_primary_hits(rt_ctx* c, const RtCamera* cam, const RtParams* p, uint32_t row0, uint32_t rows, int32_t* hit_out) {
+    int rc = check_common(c, cam, p);
+    if (rc) return rc;
+    if (!hit_out) return fail(c, RT_ERR_INVALID, "hit_out is NULL");
+    if (rows == 0 || row0 >= cam->image_height || rows > cam->image_height - row0)
+        return fail(c, RT_ERR_INVALID, "row range outside the image");
+    RT_HIP(c, hipSetDevice(c->device));
+    size_t px = (size_t)rows * cam->image_width;
+    if ((rc = ensure(c, &c->d_hits, &c->cap_hits, px * 4))) return rc;
+    RtLaunch L = make_launch(c, cam, p, row0, rows, rows, rows);
+    if ((rc = launch_hits(c, cam, p, L, c->d_hits))) return rc;
+    RT_HIP(c, hipMemcpy(hit_out, c->d_hits, px * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int rt_show_random(rt_ctx* c, uint32_t width, uint32_t height, uint64_t seed, int norm, uint8_t* rgba_out) {
+    if (!c) return RT_ERR_INVALID;
+    if (!c->module) return fail(c, RT_ERR_NO_MODULE, "no code object loaded");
+    if (!rgba_out || !width || !height || (uint64_t)width * height >= (1ull << 31))
+        return fail(c, RT_ERR_INVALID, "bad frame size or NULL output");
+    RT_HIP(c, hipSetDevice(c->device));
+    uint32_t n = width * height;
+    int rc = ensure(c, &c->d_rgba, &c->cap_rgba, (size_t)n * 4);
+    if (rc) return rc;
+    uint32_t lo = (uint32_t)(seed & 0xffffffffu), hi = (uint32_t)(seed >> 32), nm = norm ? 1u : 0u;
+    void* args[] = {&c->d_rgba, &n, &lo, &hi, &nm};
+    RT_HIP(c, hipModuleLaunchKernel(c->f_random, (n + 255u) / 256u, 1, 1, 256, 1, 1, 0, c->stream, args, nullptr));
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    RT_HIP(c, hipMemcpy(rgba_out, c->d_rgba, (size_t)n * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+float rt_last_kernel_ms(const rt_ctx* c) { return c ? c->last_ms : 0.0f; }
+
+int rt_device_info(const rt_ctx* c, char* name, size_t name_size, int* compute_units, int* clock_khz) {
+    if (!c) return RT_ERR_INVALID;
+    if (name && name_size) std::snprintf(name, name_size, "%s", c->name);
+    if (compute_units) *compute_units = c->compute_units;
+    if (clock_khz) *clock_khz = c->clock_khz;
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,429 @@
+// rt_kernels.hip -- gfx950 code object of the path tracer: one work-item per pixel, the sphere list
+// streamed from LDS (every lane of a wavefront reads the same float4 per step), counter-based PCG32
+// streams, fp32 register accumulation, gamma + RGBA8 store.  Built with
+//   hipcc --offload-arch=gfx950 --genco -O3 -ffp-contract=off
+// and loaded with hipModuleLoadData by rt_hip.cpp.  No MFMA: the work is divergent scalar fp32.
+//
+// Arithmetic contract: every floating-point operation below is written out (explicit fmaf, IEEE
+// divide and sqrt, no compiler contraction), in the order of the single-precision CPU checker, so
+// radiance and hit indices reproduce bit for bit.  The op order follows the reference's
+// gpu-implementation/src/cuda/{floatN_helper,library,ray}.cu as nvcc contracts it; citations below
+// are relative to gpu-implementation/src/cuda/ unless they name lib.rs (cpu-implementation/src/lib.rs).
+#include <hip/hip_runtime.h>
+#include "rt_device.h"
+
+#define RT_DEV __device__ __forceinline__
+
+struct V3 { float x, y, z; };
+RT_DEV V3 v3(float x, float y, float z) { V3 v; v.x = x; v.y = y; v.z = z; return v; }
+RT_DEV V3 vsub(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+RT_DEV V3 vadd(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+RT_DEV V3 vscale(V3 a, float s) { return v3(a.x * s, a.y * s, a.z * s); }
+// a.x*b.x + a.y*b.y + a.z*b.z (floatN_helper.cu:109-111) as an fma chain
+RT_DEV float vdot(V3 a, V3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
+// v * (1/|v|): stands in for rnorm3df (floatN_helper.cu:120-122); cgmath's normalize (lib.rs:44,203)
+RT_DEV V3 vunit(V3 v) { float inv = 1.0f / sqrtf(vdot(v, v)); return vscale(v, inv); }
+RT_DEV V3 ld3(const float* p) { return v3(p[0], p[1], p[2]); }
+
+// ---------------------------------------------------------------- RNG
+// PCG32 XSH-RR (library.cu:7-16), one stream per (seed, pixel, sample, k): k = 0 feeds the camera
+// jitter, k = j+1 the scatter that ends path segment j.  Seeding is pcg32_srandom_r(key, pixel) with
+// key = splitmix64 finaliser of seed ^ (sample << 32 | k).
+struct Rng { uint64_t state, inc; };
+RT_DEV uint32_t pcg_next(Rng& g) {
+    uint64_t old = g.state;
+    g.state = old * 6364136223846793005ULL + g.inc;
+    uint32_t xorshifted = (uint32_t)(((old >> 18u) ^ old) >> 27u);
+    uint32_t rot = (uint32_t)(old >> 59u);
+    return (xorshifted >> rot) | (xorshifted << ((0u - rot) & 31u));
+}
+RT_DEV uint64_t mix64(uint64_t z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+RT_DEV Rng stream_init(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t k) {
+    Rng g;
+    uint64_t key = mix64(seed ^ (((uint64_t)sample << 32) | (uint64_t)k));
+    g.inc = ((uint64_t)pixel << 1u) | 1u;
+    g.state = g.inc + key;                       // state 0 stepped once is inc; then += initstate
+    g.state = g.state * 6364136223846793005ULL + g.inc;
+    return g;
+}
+// top 24 bits -> [0,1), exact (the reference's ldexpf(u,-32), library.cu:18-24, can round to 1.0)
+RT_DEV float rand01(Rng& g) { return (float)(pcg_next(g) >> 8) * 0x1p-24f; }
+
+// Rejection in [-1,1)^3, accept p.p <= 1, normalise (lib.rs:31-47); at most 20 tries, then (1,0,0)
+// (library.cu:25-31).
+RT_DEV V3 random_unit_vector(Rng& g) {
+    V3 r = v3(1.0f, 0.0f, 0.0f);
+    bool done = false;
+    for (int i = 0; i < 20 && !done; i++) {
+        float x = fmaf(2.0f, rand01(g), -1.0f);
+        float y = fmaf(2.0f, rand01(g), -1.0f);
+        float z = fmaf(2.0f, rand01(g), -1.0f);
+        V3 p = v3(x, y, z);
+        if (vdot(p, p) <= 1.0f) { r = vunit(p); done = true; }
+    }
+    return r;
+}
+
+// ---------------------------------------------------------------- closest hit
+struct Best { float t; int idx; };
+
+// Exact acceptance of Sphere::hit (library.cu:205-218, lib.rs:103-117) for one sphere against the
+// current upper bound.  Ties keep the lower index because the bound is strict.
+RT_DEV void accept_exact(float h, float disc, float a, float t_min, int idx, Best& b) {
+    if (disc >= 0.0f) {
+        float s = sqrtf(disc);
+        float root_a = (h - s) / a;
+        float root_b = (h + s) / a;
+        float root = root_a;
+        bool ok = (t_min < root_a) && (root_a < b.t);
+        if (!ok) { root = root_b; ok = (t_min < root_b) && (root_b < b.t); }
+        if (ok) { b.t = root; b.idx = idx; }
+    }
+}
+
+// Scan `count` (a multiple of RT_SCAN_UNROLL) spheres staged in LDS.  Per sphere and lane:
+//   oc = c - o; h = d.oc; ncc = r*r - oc.oc (accumulated from r*r down); disc = h*h + a*ncc
+// 13 VALU operations, of which the last two form a cheap superset test of "can this sphere be hit":
+// a root in (t_min, ..) with t_min >= 0 needs disc >= 0 and (h > 0 or the origin inside the sphere,
+// ncc > 0), so a lane is a candidate when the sign bit of ((h & ncc) | disc) is clear.  Only then is
+// the exact test (sqrt, two divides) run.
+RT_DEV void scan_tile(const float4* __restrict__ tile, uint32_t count, int base,
+                      V3 o, V3 d, float a, float t_min, Best& b) {
+    for (uint32_t i = 0; i < count; i += RT_SCAN_UNROLL) {
+        float4 s[RT_SCAN_UNROLL];
+#pragma unroll
+        for (uint32_t u = 0; u < RT_SCAN_UNROLL; u++) s[u] = tile[i + u];
+#pragma unroll
+        for (uint32_t u = 0; u < RT_SCAN_UNROLL; u++) {
+            float ocx = s[u].x - o.x, ocy = s[u].y - o.y, ocz = s[u].z - o.z;
+            float h = fmaf(d.z, ocz, fmaf(d.y, ocy, d.x * ocx));
+            float ncc = fmaf(-ocz, ocz, fmaf(-ocy, ocy, fmaf(-ocx, ocx, s[u].w)));
+            float disc = fmaf(h, h, a * ncc);
+            int key = (__float_as_int(h) & __float_as_int(ncc)) | __float_as_int(disc);
+            if (key >= 0) accept_exact(h, disc, a, t_min, base + (int)(i + u), b);
+        }
+    }
+}
+
+// ---------------------------------------------------------------- shading
+struct Scene {
+    const float4* __restrict__ geom;    // {cx, cy, cz, r*r}, n_padded entries
+    const float4* __restrict__ surf;    // {radius, param, material bits, 0}
+    const float4* __restrict__ albedo;  // {r, g, b, 0}
+};
+
+struct HitInfo { V3 p, n; bool front; };
+
+// Hit record of the closest sphere: point, normal facing the ray (library.cu:220-225, lib.rs:118-122).
+RT_DEV HitInfo finish_hit(const Scene& sc, int idx, float t, V3 o, V3 d, float radius, uint32_t flags) {
+    HitInfo h;
+    float4 g = sc.geom[idx];
+    V3 c = v3(g.x, g.y, g.z);
+    h.p = v3(fmaf(d.x, t, o.x), fmaf(d.y, t, o.y), fmaf(d.z, t, o.z));
+    V3 pc = vsub(h.p, c);
+    V3 n = v3(pc.x / radius, pc.y / radius, pc.z / radius);
+    float nd = vdot(n, d);
+    bool flip = (flags & RT_FLAG_FLIP_SIGNBIT) ? !(__float_as_int(nd) < 0)   // lib.rs:49-58
+                                               : (nd > 0.0f);                // floatN_helper.cu:129-136
+    if (flip) n = v3(-n.x, -n.y, -n.z);
+    h.n = n;
+    h.front = !flip;
+    return h;
+}
+
+// (1-a)*white + a*(0.5,0.7,1.0), a = blend*(unit(d).y + 1)  (ray.cu:43-45, lib.rs:203-205)
+RT_DEV V3 sky(V3 d, float blend) {
+    V3 u = vunit(d);
+    float a = blend * (u.y + 1.0f);
+    float om = 1.0f - a;
+    return v3(fmaf(a, 0.5f, om), fmaf(a, 0.7f, om), fmaf(a, 1.0f, om));
+}
+
+// Material::scatter (library.cu:131-149,175-183) plus the book's dielectric.  Draw order: one uniform
+// (dielectric choice), then the unit-vector rejection triples.
+RT_DEV V3 scatter(uint32_t mat, float param, V3 d, const HitInfo& h, Rng& g, uint32_t flags) {
+    float u_choice = rand01(g);
+    V3 ru = random_unit_vector(g);
+    V3 n = h.n;
+    V3 out;
+    if ((flags & RT_FLAG_BAND_ALBEDO) || mat == RT_MAT_DIFFUSE) {
+        out = vadd(n, ru);                                       // library.cu:132, lib.rs:194
+        if (!(flags & RT_FLAG_BAND_ALBEDO)) {
+            const float s = 1e-8f;                               // floatN_helper.cu:116-119
+            if (fabsf(out.x) < s && fabsf(out.y) < s && fabsf(out.z) < s) out = n;
+        }
+    } else if (mat == RT_MAT_REFLECT) {
+        float k = 2.0f * vdot(d, n);                             // floatN_helper.cu:124-127
+        V3 refl = v3(fmaf(-n.x, k, d.x), fmaf(-n.y, k, d.y), fmaf(-n.z, k, d.z));
+        V3 ur = vunit(refl);                                     // library.cu:146-147
+        out = v3(fmaf(ru.x, param, ur.x), fmaf(ru.y, param, ur.y), fmaf(ru.z, param, ur.z));
+    } else {
+        // Dielectric ("Ray Tracing in One Weekend" section 11): Snell refraction, Schlick reflectance.
+        float ri = h.front ? 1.0f / param : param;
+        V3 ud = vunit(d);
+        float udn = vdot(ud, n);
+        float cos_t = fminf(-udn, 1.0f);
+        float sin_t = sqrtf(fmaf(-cos_t, cos_t, 1.0f));
+        bool cannot = ri * sin_t > 1.0f;
+        float r0 = (1.0f - ri) / (1.0f + ri);
+        r0 = r0 * r0;
+        float x = 1.0f - cos_t;
+        float x2 = x * x;
+        float x5 = x2 * x2 * x;
+        float prob = fmaf(1.0f - r0, x5, r0);
+        if (cannot || prob > u_choice) {
+            float k = 2.0f * udn;
+            out = v3(fmaf(-n.x, k, ud.x), fmaf(-n.y, k, ud.y), fmaf(-n.z, k, ud.z));
+        } else {
+            V3 perp = v3(ri * fmaf(cos_t, n.x, ud.x), ri * fmaf(cos_t, n.y, ud.y), ri * fmaf(cos_t, n.z, ud.z));
+            float par = -sqrtf(fabsf(1.0f - vdot(perp, perp)));
+            out = v3(fmaf(par, n.x, perp.x), fmaf(par, n.y, perp.y), fmaf(par, n.z, perp.z));
+        }
+    }
+    return out;
+}
+
+// Primary ray of pixel (i,j) with sub-pixel offset (si,sj): ray.cu:62-77 / lib.rs:215-217.
+RT_DEV void make_ray(const RtCamera& cam, uint32_t i, uint32_t j, float si, float sj, V3& o, V3& d) {
+    float fx = (float)i + si, fy = (float)j + sj;
+    V3 pc;
+    pc.x = cam.pixel00_loc[0] + fmaf(cam.pixel_delta_u[0], fx, cam.pixel_delta_v[0] * fy);
+    pc.y = cam.pixel00_loc[1] + fmaf(cam.pixel_delta_u[1], fx, cam.pixel_delta_v[1] * fy);
+    pc.z = cam.pixel00_loc[2] + fmaf(cam.pixel_delta_u[2], fx, cam.pixel_delta_v[2] * fy);
+    o = ld3(cam.center);
+    d = vsub(pc, o);
+}
+
+RT_DEV void sample_ray(const RtCamera& cam, const RtLaunch& L, uint64_t seed, uint32_t x, uint32_t y,
+                       uint32_t pixel, uint32_t s, V3& o, V3& d) {
+    float si, sj;
+    if (L.flags & RT_FLAG_SAMPLER_GRID) {                        // ray.cu:59-60
+        uint32_t n2 = L.sample2_per_pixel;
+        si = (float)(s % n2) / (float)n2;
+        sj = (float)(s / n2) / (float)n2;
+    } else {                                                     // lib.rs:209-214
+        Rng g = stream_init(seed, pixel, s, 0u);
+        si = rand01(g) - 0.5f;
+        sj = rand01(g) - 0.5f;
+    }
+    make_ray(cam, x, y, si, sj, o, d);
+}
+
+RT_DEV uint32_t quant(float lin, uint32_t flags) {
+    float v = sqrtf(lin) * 255.0f;                               // gamma 2: lib.rs:236, ray.cu:129
+    if (flags & RT_FLAG_QUANT_ROUND) {                           // (x.sqrt()*255.0).round() as u8
+        if (!(v == v)) return 0u;
+        float r = roundf(v);
+        if (r <= 0.0f) return 0u;
+        if (r >= 255.0f) return 255u;
+        return (uint32_t)r;
+    }
+    if (!(v == v)) return 255u;                                  // ray.cu:81-89: fminf drops a NaN
+    float c = v < 255.0f ? v : 255.0f;
+    c = c > 0.0f ? c : 0.0f;
+    return (uint32_t)c;
+}
+
+// Wave tile -> pixel.  A wavefront owns an 8x8 pixel tile; consecutive tiles of a workgroup sit side
+// by side in a row.  Returns false for lanes outside the image / row set.
+RT_DEV bool map_pixel(const RtLaunch& L, uint32_t wave_tile, uint32_t lane, uint32_t& x, uint32_t& ly, uint32_t& y) {
+    uint32_t tx = wave_tile % L.tiles_x, ty = wave_tile / L.tiles_x;
+    x = tx * 8u + (lane & 7u);
+    ly = ty * 8u + (lane >> 3u);
+    uint32_t k = ly / L.tile_rows;
+    y = L.row_base + k * L.tile_stride_rows + (ly - k * L.tile_rows);
+    return wave_tile < L.n_wave_tiles && x < L.width && ly < L.rows_local && y < L.height;
+}
+
+RT_DEV void stage_tile(float4* tile, const float4* __restrict__ geom, uint32_t first, uint32_t count) {
+    for (uint32_t i = threadIdx.x; i < count; i += blockDim.x) tile[i] = geom[first + i];
+}
+
+extern __shared__ float4 rt_lds_tile[];
+
+// ---------------------------------------------------------------- render
+// MULTI = false: the whole (padded) sphere list fits the LDS tile; staged once, after which every
+//                wavefront runs on its own until its 64 pixels are finished.
+// MULTI = true : the list is streamed tile by tile; the workgroup moves in lock step, one path
+//                segment per outer iteration.
+// Each lane walks its pixel's samples back to back: when a path ends, the lane starts the pixel's next
+// sample in the following iteration instead of idling until its neighbours' paths end.  Samples are
+// still accumulated in sample order, so the sum is the one the nested loops of ray.cu:125-127 give.
+template <bool MULTI>
+RT_DEV void render_body(const Scene& sc, uint32_t* __restrict__ rgba, float4* __restrict__ linear,
+                        unsigned long long* __restrict__ segments, const RtCamera& cam, const RtLaunch& L) {
+    float4* tile = rt_lds_tile;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave_tile = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint64_t seed = ((uint64_t)L.seed_hi << 32) | L.seed_lo;
+    const uint32_t flags = L.flags;
+
+    uint32_t x, ly, y;
+    const bool valid = map_pixel(L, wave_tile, lane, x, ly, y);
+    const uint32_t pixel = y * L.width + x;
+
+    if (!MULTI) {
+        stage_tile(tile, sc.geom, 0u, L.n_padded);
+        __syncthreads();
+    }
+
+    float band = 0.0f;
+    if (flags & RT_FLAG_BAND_ALBEDO) {                           // lib.rs:225-226
+        uint32_t gi = L.width / 5u;
+        band = 0.1f + 0.2f * (float)(x / (gi ? gi : 1u));
+    }
+
+    const uint32_t spp = (valid && L.max_depth > 0u) ? L.samples_per_pixel : 0u;
+    uint32_t s = 0u, seg = 0u, nb = 0u;
+    unsigned long long nseg = 0ull;
+    V3 total = v3(0.0f, 0.0f, 0.0f), thr = v3(1.0f, 1.0f, 1.0f);
+    V3 o = v3(0.0f, 0.0f, 0.0f), d = v3(0.0f, 0.0f, 1.0f);
+    if (s < spp) sample_ray(cam, L, seed, x, y, pixel, s, o, d);
+
+    for (;;) {
+        const bool active = s < spp;
+        if (MULTI) {
+            if (!__syncthreads_or(active ? 1 : 0)) break;
+        } else {
+            if (__ballot(active) == 0ull) break;
+        }
+        Best b;
+        b.t = L.t_max;
+        b.idx = -1;
+        const float a = vdot(d, d);                              // hoisted d.d (library.cu:201)
+        if (MULTI) {
+            for (uint32_t first = 0u; first < L.n_padded; first += RT_TILE_SPHERES) {
+                uint32_t count = L.n_padded - first;
+                if (count > RT_TILE_SPHERES) count = RT_TILE_SPHERES;
+                if (first) __syncthreads();                      // previous tile fully scanned
+                stage_tile(tile, sc.geom, first, count);
+                __syncthreads();
+                if (active) scan_tile(tile, count, (int)first, o, d, a, L.t_min, b);
+            }
+        } else {
+            if (active) scan_tile(tile, L.n_padded, 0, o, d, a, L.t_min, b);
+        }
+        if (active) {
+            nseg++;
+            bool path_done;
+            V3 color;
+            if (b.idx >= 0) {                                    // ray.cu:35-40
+                float4 sf = sc.surf[b.idx];
+                uint32_t mat = (uint32_t)__float_as_int(sf.z);
+                HitInfo h = finish_hit(sc, b.idx, b.t, o, d, sf.x, flags);
+                Rng g = stream_init(seed, pixel, s, seg + 1u);
+                V3 nd = scatter(mat, sf.y, d, h, g, flags);
+                o = h.p;
+                d = nd;
+                if (flags & RT_FLAG_BAND_ALBEDO) {
+                    nb++;
+                } else {
+                    float4 al = sc.albedo[b.idx];
+                    thr = v3(thr.x * al.x, thr.y * al.y, thr.z * al.z);   // ray.cu:37
+                }
+                seg++;
+                path_done = (seg == L.max_depth);                // ray.cu:30-32, lib.rs:190-192
+                color = v3(0.0f, 0.0f, 0.0f);
+            } else {
+                if (flags & RT_FLAG_BAND_ALBEDO) {               // lib.rs:195-205, innermost call outwards
+                    color = sky(d, band);
+                    for (uint32_t k = 0u; k < nb; k++) color = v3(band * color.x, band * color.y, band * color.z);
+                } else {
+                    V3 sk = sky(d, 0.5f);
+                    color = v3(thr.x * sk.x, thr.y * sk.y, thr.z * sk.z);  // ray.cu:45
+                }
+                path_done = true;
+            }
+            if (path_done) {
+                total = vadd(total, color);                      // ray.cu:126, lib.rs:230
+                s++;
+                seg = 0u;
+                nb = 0u;
+                thr = v3(1.0f, 1.0f, 1.0f);
+                if (s < spp) sample_ray(cam, L, seed, x, y, pixel, s, o, d);
+            }
+        }
+    }
+
+    if (valid) {
+        float fs = (float)L.samples_per_pixel;
+        V3 mean = v3(total.x / fs, total.y / fs, total.z / fs);  // ray.cu:129, lib.rs:231
+        size_t k = (size_t)ly * L.width + x;
+        rgba[k] = quant(mean.x, flags) | (quant(mean.y, flags) << 8) | (quant(mean.z, flags) << 16) | (255u << 24);
+        if (linear) linear[k] = make_float4(mean.x, mean.y, mean.z, 1.0f);
+    }
+    if (segments) {
+        // one 64-bit atomic per wavefront
+        for (int off = 32; off > 0; off >>= 1) nseg += __shfl_xor(nseg, off);
+        if (lane == 0u && nseg) atomicAdd(segments, nseg);
+    }
+}
+
+extern "C" __global__ void __launch_bounds__(1024)
+rt_render(const float4* geom, const float4* surf, const float4* albedo, uint32_t* rgba, float4* linear,
+          unsigned long long* segments, RtCamera cam, RtLaunch L) {
+    Scene sc = {geom, surf, albedo};
+    render_body<false>(sc, rgba, linear, segments, cam, L);
+}
+
+extern "C" __global__ void __launch_bounds__(1024)
+rt_render_stream(const float4* geom, const float4* surf, const float4* albedo, uint32_t* rgba, float4* linear,
+                 unsigned long long* segments, RtCamera cam, RtLaunch L) {
+    Scene sc = {geom, surf, albedo};
+    render_body<true>(sc, rgba, linear, segments, cam, L);
+}
+
+// ---------------------------------------------------------------- primary-hit index map
+// Closest sphere index (or -1) of the ray through each pixel centre (sub-pixel offset 0).
+extern "C" __global__ void __launch_bounds__(1024)
+rt_primary_hits(const float4* geom, int32_t* hits, RtCamera cam, RtLaunch L) {
+    float4* tile = rt_lds_tile;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave_tile = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    uint32_t x, ly, y;
+    const bool valid = map_pixel(L, wave_tile, lane, x, ly, y);
+    V3 o, d;
+    make_ray(cam, x, y, 0.0f, 0.0f, o, d);
+    const float a = vdot(d, d);
+    Best b;
+    b.t = L.t_max;
+    b.idx = -1;
+    for (uint32_t first = 0u; first < L.n_padded; first += RT_TILE_SPHERES) {
+        uint32_t count = L.n_padded - first;
+        if (count > RT_TILE_SPHERES) count = RT_TILE_SPHERES;
+        if (first) __syncthreads();
+        stage_tile(tile, geom, first, count);
+        __syncthreads();
+        if (valid) scan_tile(tile, count, (int)first, o, d, a, L.t_min, b);
+    }
+    if (valid) hits[(size_t)ly * L.width + x] = b.idx;
+}
+
+// ---------------------------------------------------------------- RNG debug views (ray.cu:114-118)
+extern "C" __global__ void __launch_bounds__(1024)
+rt_show_random(uint32_t* rgba, uint32_t n_pixels, uint32_t seed_lo, uint32_t seed_hi, uint32_t norm) {
+    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_pixels) return;
+    Rng g = stream_init(((uint64_t)seed_hi << 32) | seed_lo, p, 0u, 0u);
+    V3 c;
+    if (norm) {
+        c = random_unit_vector(g);
+    } else {
+        c.x = rand01(g); c.y = rand01(g); c.z = rand01(g);
+    }
+    // to_pixel without gamma (ray.cu:81-89,116)
+    float v[3] = {c.x * 255.0f, c.y * 255.0f, c.z * 255.0f};
+    uint32_t q[3];
+    for (int k = 0; k < 3; k++) {
+        float t = v[k];
+        if (!(t == t)) { q[k] = 255u; continue; }
+        t = t < 255.0f ? t : 255.0f;
+        t = t > 0.0f ? t : 0.0f;
+        q[k] = (uint32_t)t;
+    }
+    rgba[p] = q[0] | (q[1] << 8) | (q[2] << 16) | (255u << 24);
+}

@@ -80,9 +80,9 @@ def lib():
         L.or_u01.restype = C.c_float
         L.or_u01.argtypes = [C.c_uint32]
         L.or64_camera_new.argtypes = [C.c_double, C.c_uint32, C.POINTER(OrCameraD)]
-        L.or32_camera_initialize.argtypes = [C.POINTER(RtCamera)]
-        L.or32_camera_from_rt.argtypes = [C.POINTER(RtCamera), C.POINTER(OrCameraF)]
-        L.or64_camera_from_rt.argtypes = [C.POINTER(RtCamera), C.POINTER(OrCameraD)]
+        L.or32_camera_initialize.argtypes = [C.c_void_p]
+        L.or32_camera_from_rt.argtypes = [C.c_void_p, C.POINTER(OrCameraF)]
+        L.or64_camera_from_rt.argtypes = [C.c_void_p, C.POINTER(OrCameraD)]
         L.or32_camera_from_d.argtypes = [C.POINTER(OrCameraD), C.POINTER(OrCameraF)]
         vp = C.c_void_p
         L.or64_pixel_center_ray.argtypes = [C.POINTER(OrCameraD), C.c_uint32, C.c_uint32, vp, vp]
@@ -93,9 +93,9 @@ def lib():
                                         C.c_uint32, C.c_uint32, C.c_int, vp, vp, vp, vp]
         L.or32_primary_hits.argtypes = [C.POINTER(OrCameraF), vp, C.c_uint32, C.c_float, C.c_float, C.c_uint32,
                                         C.c_uint32, C.c_uint32, C.c_int, vp, vp, vp, vp]
-        L.or64_render.argtypes = [C.POINTER(OrCameraD), vp, C.c_uint32, C.POINTER(RtParams), C.c_uint32, C.c_uint32,
+        L.or64_render.argtypes = [C.POINTER(OrCameraD), vp, C.c_uint32, vp, C.c_uint32, C.c_uint32,
                                   C.c_int, vp, vp, C.POINTER(C.c_uint64)]
-        L.or32_render.argtypes = [C.POINTER(OrCameraF), vp, C.c_uint32, C.POINTER(RtParams), C.c_uint32, C.c_uint32,
+        L.or32_render.argtypes = [C.POINTER(OrCameraF), vp, C.c_uint32, vp, C.c_uint32, C.c_uint32,
                                   C.c_int, vp, vp, C.POINTER(C.c_uint64)]
         L.or32_show_random.argtypes = [C.c_uint32, C.c_uint32, C.c_uint64, C.c_int, vp]
         _lib = L
@@ -128,14 +128,16 @@ def camera_f32_from_d(camd):
 
 
 def camera_f32_from_rt(rt):
+    """`rt` is any ctypes structure with the 148-byte RtCamera layout (the product's or this module's)."""
+    assert C.sizeof(rt) == 148
     cam = OrCameraF()
-    lib().or32_camera_from_rt(C.byref(rt), C.byref(cam))
+    lib().or32_camera_from_rt(C.addressof(rt), C.byref(cam))
     return cam
 
 
 def camera_f64_from_rt(rt):
     cam = OrCameraD()
-    lib().or64_camera_from_rt(C.byref(rt), C.byref(cam))
+    lib().or64_camera_from_rt(C.addressof(rt), C.byref(cam))
     return cam
 
 
@@ -169,7 +171,7 @@ def render(cam, spheres, params, row0=0, rows=None, threads=None):
     lin = np.empty((rows, W, 4), np.float64 if f64 else np.float32)
     seg = C.c_uint64(0)
     fn = lib().or64_render if f64 else lib().or32_render
-    fn(C.byref(cam), _ptr(sp), len(sp), C.byref(params), row0, rows, threads or default_threads(),
+    fn(C.byref(cam), _ptr(sp), len(sp), C.addressof(params), row0, rows, threads or default_threads(),
        _ptr(rgba), _ptr(lin), C.byref(seg))
     return rgba, lin, seg.value
 

@@ -1,0 +1,31 @@
+"""Quick single-GPU throughput probe: book-1 final scene, kernel time from the library's HIP events."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import ray_tracing_amd as rt
+
+width = int(sys.argv[1]) if len(sys.argv) > 1 else 1920
+spp = int(sys.argv[2]) if len(sys.argv) > 2 else 16
+depth = int(sys.argv[3]) if len(sys.argv) > 3 else 50
+block = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+scene = sys.argv[5] if len(sys.argv) > 5 else "book1"
+if scene == "book1":
+    sp = rt.scene_book1_final(1); cam = rt.Camera.look_at(16 / 9, width, 20.0, (13, 2, 3), (0, 0, 0))
+elif scene == "grid":
+    sp = rt.scene_grid(2, 128); cam = rt.Camera.look_at(16 / 9, width, 40.0, (0, 30, 80), (0, 0, 0))
+elif scene == "hall":
+    sp = rt.scene_mirror_hall(3, 64); cam = rt.Camera.look_at(16 / 9, width, 90.0, (0, 0, -85), (0, 0, -70))
+else:
+    sp = rt.scene_cpu_default(); cam = rt.Camera.new_cpu(16 / 9, width)
+p = rt.cpu_params(spp, depth, block_dim=block) if scene == "cpu" else rt.DeviceGUI(samples_per_pixel=spp, max_depth=depth, seed=1, block_dim=block)
+w = rt.HipWorld(0, sp)
+print(w.device_info())
+n = len(sp)
+for it in range(3):
+    t0 = time.time()
+    r = w.render(cam, p)
+    dt = time.time() - t0
+    ms = r["kernel_ms"]
+    flops = r["rays"] * (18 * n + 64)
+    print(f"{scene} {cam.image_width}x{cam.image_height} spp={spp} depth={depth} n={n}: rays={r['rays']} "
+          f"({r['rays'] / (cam.image_width * cam.image_height * spp):.2f}/sample) kernel {ms:.2f} ms wall {dt * 1e3:.1f} ms "
+          f"-> {r['rays'] / ms * 1e-3:.1f} Mrays/s, {flops / ms * 1e-9:.2f} TFLOP/s ({flops / ms * 1e-9 / 157.3 * 100:.1f}% of 157.3)", flush=True)
