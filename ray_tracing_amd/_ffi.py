@@ -4,6 +4,7 @@ The library is built in-tree by ``__graft_entry__.build()`` (``make -C ray_traci
 There is no fallback: if the shared object is missing, importing this module raises.
 """
 import ctypes as C
+import importlib.util
 import os
 
 import numpy as np
@@ -72,6 +73,18 @@ SYMBOLS = {
 _lib = None
 
 
+def _share_hip_runtime_with_torch():
+    """PyTorch-ROCm wheels carry their own libamdhip64.so.7.  Two HIP runtimes in one process cannot both own
+    the GPU, so when torch is installed its copy is loaded first (without importing torch); librt_hip.so's
+    DT_NEEDED entry has the same soname and binds to it.  Without torch the library uses /opt/rocm/lib."""
+    spec = importlib.util.find_spec("torch")
+    if spec is None or not spec.origin:
+        return
+    hip = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(hip):
+        C.CDLL(hip, mode=C.RTLD_GLOBAL)
+
+
 def lib():
     """The loaded C-ABI library; raises if it has not been built."""
     global _lib
@@ -80,6 +93,7 @@ def lib():
             raise ImportError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "or `make -C ray_tracing_amd/csrc` (there is no CPU fallback)")
+        _share_hip_runtime_with_torch()
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(L, name)  # AttributeError if the library does not export it
