@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mrays/s (primary + bounce ray segments) of the path-tracing hot path on MI355X.
+
+Workload (N = 1 and N > 1 alike): the "Ray Tracing in One Weekend" final scene (485 spheres, mixed
+Lambertian / metal / dielectric), 3840x2160, 500 samples per pixel, depth 50 -- the configuration the
+target metric is quoted on.  One step = one full frame.  With N GPUs the frame is dealt out as
+interleaved 8-row tiles (rank r renders tiles r, r+N, ...; total work fixed = strong scaling) and the
+finished tiles are gathered to rank 0 with RCCL inside the timed region.
+
+    python bench.py                      # 1 GPU, defaults
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints one JSON line.  `value` counts every ray segment all ranks traced in the K timed steps
+(in-kernel counters) divided by the max-over-ranks wall time.  `roofline` prices the render kernel
+against the FP32 vector peak with the algorithmic FLOP count 18*N_spheres + 64 per segment and the
+kernel's own duration (HIP events on the launch stream, inside the library).  `cpu_baseline` times the
+double-precision CPU restatement of the reference (oracle/, test infrastructure) on a bounded sample of
+the same scene on this host's cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+FP32_VECTOR_PEAK_TFLOPS = 157.3   # MI355X vector FP32 peak: 256 CU x 2.4 GHz x 256 FLOP/clk/CU
+TILE_ROWS = 8
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--width", type=int, default=3840)
+    ap.add_argument("--spp", type=int, default=500)
+    ap.add_argument("--depth", type=int, default=50)
+    ap.add_argument("--block-dim", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-width", type=int, default=1920)
+    ap.add_argument("--cpu-spp", type=int, default=32)
+    return ap.parse_args()
+
+
+def cpu_baseline(rt, spheres, depth):
+    """The f64 restatement of cpu-implementation/src/lib.rs on this host's cores, bounded sample."""
+    import oracle_ffi
+    args = ARGS
+    cam = rt.Camera.look_at(16.0 / 9.0, args.cpu_width, 20.0, (13.0, 2.0, 3.0), (0.0, 0.0, 0.0))
+    p = rt.DeviceGUI(samples_per_pixel=args.cpu_spp, max_depth=depth, seed=1)
+    threads = oracle_ffi.default_threads()
+    ocam = oracle_ffi.camera_f64_from_rt(cam.block)
+    t0 = time.perf_counter()
+    _, _, seg = oracle_ffi.render(ocam, spheres, p, threads=threads)
+    dt = time.perf_counter() - t0
+    return {"value": seg / dt * 1e-6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "sample": f"book-1 final scene {cam.image_width}x{cam.image_height}, {args.cpu_spp} spp, depth {depth}, "
+                      f"same camera and seed; f64 restatement of lib.rs, {seg} segments in {dt:.1f} s"}
+
+
+def main():
+    args = ARGS
+    import torch
+    import torch.distributed as dist
+    import ray_tracing_amd as rt
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+        if world == 1 and args.gpus > 1:
+            sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    spheres = rt.scene_book1_final(1)
+    cam = rt.Camera.look_at(16.0 / 9.0, args.width, 20.0, (13.0, 2.0, 3.0), (0.0, 0.0, 0.0))
+    W, H = cam.image_width, cam.image_height
+    params = rt.DeviceGUI(samples_per_pixel=args.spp, max_depth=args.depth, seed=1, block_dim=args.block_dim)
+    hip = rt.HipWorld(local_rank, spheres)
+
+    n_tiles = (H + TILE_ROWS - 1) // TILE_ROWS
+    my_tiles = len(range(rank, n_tiles, world))
+    max_tiles = (n_tiles + world - 1) // world
+    # compact per-rank buffer, padded to the largest per-rank tile count so the gather is uniform
+    d_rgba = torch.zeros((max_tiles * TILE_ROWS, W, 4), dtype=torch.uint8, device=dev)
+    gathered = [torch.empty_like(d_rgba) for _ in range(world)] if (world > 1 and rank == 0) else None
+
+    def step():
+        rays, ms = hip.render_tiles_device(cam, params, TILE_ROWS, rank, world, my_tiles, d_rgba.data_ptr())
+        frame = None
+        if world > 1:
+            dist.gather(d_rgba, gathered, dst=0)          # RCCL over xGMI; 8-row tiles, <= 4.2 MB per peer at 4K
+            if rank == 0:
+                # tile t = k*world + r sits at gathered[r][k]: stack as [k][r] and flatten
+                g = torch.stack(gathered, 0).view(world, max_tiles, TILE_ROWS, W, 4)
+                frame = g.permute(1, 0, 2, 3, 4).reshape(max_tiles * world * TILE_ROWS, W, 4)[:H]
+        else:
+            frame = d_rgba[:H]
+        return rays, ms, frame
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    rays_total, kernel_ms = 0, []
+    frame = None
+    for _ in range(args.steps):
+        rays, ms, frame = step()
+        rays_total += rays
+        kernel_ms.append(ms)
+    fence()
+    elapsed = time.perf_counter() - t0
+
+    stats = torch.tensor([elapsed, float(rays_total), sum(kernel_ms) / max(1, len(kernel_ms))], dtype=torch.float64, device=dev)
+    if world > 1:
+        tmax = stats.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = stats.clone()
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        elapsed_max, rays_all, kms_max = tmax[0].item(), tsum[1].item(), tmax[2].item()
+    else:
+        elapsed_max, rays_all, kms_max = stats[0].item(), stats[1].item(), stats[2].item()
+
+    if rank == 0:
+        n_sph = len(spheres)
+        flop_per_segment = 18 * n_sph + 64
+        # dominant kernel = rt_render on this rank: its own segments over its own average duration
+        rank0_rays_per_launch = rays_total / max(1, args.steps)
+        k_ms = sum(kernel_ms) / max(1, len(kernel_ms))
+        achieved = rank0_rays_per_launch * flop_per_segment / (k_ms * 1e-3) * 1e-12 if k_ms > 0 else 0.0
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+        if os.path.exists(pmc) and world == 1 and (args.width, args.spp, args.depth) == (3840, 500, 50):
+            try:
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Mrays/s (primary+bounce) at 1/2/4/8 MI355X + % of FP32 VALU peak",
+            "value": rays_all / elapsed_max * 1e-6,
+            "unit": "Mrays/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed_max / max(1, args.steps) * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"book-1 final scene, {n_sph} spheres, {W}x{H}, {args.spp} spp, max depth {args.depth}, "
+                                   f"jittered sampler, seed 1; frame split into interleaved {TILE_ROWS}-row tiles over "
+                                   f"{world} GPU(s), RCCL gather to rank 0",
+                       "spheres": n_sph, "width": W, "height": H, "spp": args.spp, "max_depth": args.depth,
+                       "segments_per_frame": rays_all / max(1, args.steps), "parallelism": f"rowtiles{world}"},
+            "roofline": {"bound": "valu_fp32", "achieved": achieved, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / FP32_VECTOR_PEAK_TFLOPS, "traffic": traffic,
+                         "kernel": "rt_render", "kernel_ms": k_ms, "flop_per_segment": flop_per_segment,
+                         "segments_per_launch": rank0_rays_per_launch},
+            "kernel_ms_max_over_ranks": kms_max,
+            "checksum": int(frame.to(torch.int64).sum().item()) if frame is not None else None,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(rt, spheres, args.depth)
+        print(json.dumps(out), flush=True)
+    hip.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    ARGS = parse()
+    main()

@@ -30,5 +30,8 @@ typedef struct RtLaunch {
 // Spheres staged in LDS at a time: 4096 x 16 B = 64 KiB.  Scenes up to this size are staged once per
 // workgroup; larger ones are streamed through the same buffer tile by tile.
 #define RT_TILE_SPHERES 4096u
+// Candidate slots per lane (u16 each, in LDS); a wavefront drains its lists when a lane holds more than
+// RT_CAND_CAP - RT_SCAN_UNROLL, so a scan step can never overflow them.
+#define RT_CAND_CAP 24u
 
 #endif

@@ -144,9 +144,10 @@ void launch_geometry(const RtParams* p, const RtLaunch& L, unsigned* grid, unsig
     *grid = (L.n_wave_tiles + waves - 1u) / waves;
 }
 
-size_t lds_bytes(const rt_ctx* c) {
+// Dynamic LDS per workgroup: the sphere tile plus one candidate-list block per wavefront.
+size_t lds_bytes(const rt_ctx* c, unsigned block) {
     uint32_t n = c->n_padded < RT_TILE_SPHERES ? c->n_padded : RT_TILE_SPHERES;
-    return (size_t)n * 16u;
+    return (size_t)n * 16u + (size_t)(block / 64u) * RT_CAND_CAP * 64u * 2u;
 }
 
 // One render launch into device buffers; blocking; fills last_ms and (optionally) the segment count.
@@ -161,7 +162,7 @@ int launch_render(rt_ctx* c, const RtCamera* cam, const RtParams* p, RtLaunch L,
     hipFunction_t f = (c->n_padded <= RT_TILE_SPHERES) ? c->f_render : c->f_render_stream;
     RT_HIP(c, hipEventRecord(c->ev0, c->stream));
     if (grid > 0)
-        RT_HIP(c, hipModuleLaunchKernel(f, grid, 1, 1, block, 1, 1, (unsigned)lds_bytes(c), c->stream, args, nullptr));
+        RT_HIP(c, hipModuleLaunchKernel(f, grid, 1, 1, block, 1, 1, (unsigned)lds_bytes(c, block), c->stream, args, nullptr));
     RT_HIP(c, hipEventRecord(c->ev1, c->stream));
     RT_HIP(c, hipStreamSynchronize(c->stream));
     RT_HIP(c, hipEventElapsedTime(&c->last_ms, c->ev0, c->ev1));
@@ -175,7 +176,7 @@ int launch_hits(rt_ctx* c, const RtCamera* cam, const RtParams* p, RtLaunch L, v
     RtCamera cam_copy = *cam;
     void* args[] = {&c->d_geom, &d_hits, &cam_copy, &L};
     if (grid > 0)
-        RT_HIP(c, hipModuleLaunchKernel(c->f_hits, grid, 1, 1, block, 1, 1, (unsigned)lds_bytes(c), c->stream, args, nullptr));
+        RT_HIP(c, hipModuleLaunchKernel(c->f_hits, grid, 1, 1, block, 1, 1, (unsigned)lds_bytes(c, block), c->stream, args, nullptr));
     RT_HIP(c, hipStreamSynchronize(c->stream));
     return 0;
 }

@@ -85,28 +85,60 @@ RT_DEV void accept_exact(float h, float disc, float a, float t_min, int idx, Bes
     }
 }
 
-// Scan `count` (a multiple of RT_SCAN_UNROLL) spheres staged in LDS.  Per sphere and lane:
+// The three per-sphere terms, in the checker's op order:
 //   oc = c - o; h = d.oc; ncc = r*r - oc.oc (accumulated from r*r down); disc = h*h + a*ncc
-// 13 VALU operations, of which the last two form a cheap superset test of "can this sphere be hit":
-// a root in (t_min, ..) with t_min >= 0 needs disc >= 0 and (h > 0 or the origin inside the sphere,
-// ncc > 0), so a lane is a candidate when the sign bit of ((h & ncc) | disc) is clear.  Only then is
-// the exact test (sqrt, two divides) run.
+RT_DEV void sphere_terms(float4 s, V3 o, V3 d, float a, float& h, float& ncc, float& disc) {
+    float ocx = s.x - o.x, ocy = s.y - o.y, ocz = s.z - o.z;
+    h = fmaf(d.z, ocz, fmaf(d.y, ocy, d.x * ocx));
+    ncc = fmaf(-ocz, ocz, fmaf(-ocy, ocy, fmaf(-ocx, ocx, s.w)));
+    disc = fmaf(h, h, a * ncc);
+}
+
+// Per-lane list of candidate spheres of the tile being scanned, kept in LDS as a column of a
+// [RT_CAND_CAP][64] u16 array per wavefront (lane l owns column l, so pushes never conflict).
+struct Cand { uint16_t* col; uint32_t n; };
+
+// Runs the exact test on every listed sphere, in list (= index) order.  Lanes with shorter lists idle
+// for the extra rounds; the terms are recomputed from the staged sphere, bit for bit those of the scan.
+RT_DEV void drain(const float4* __restrict__ tile, int base, Cand& c, V3 o, V3 d, float a, float t_min, Best& b) {
+    for (uint32_t k = 0; __ballot(k < c.n) != 0ull; k++) {
+        if (k < c.n) {
+            uint32_t i = c.col[k * 64u];
+            float h, ncc, disc;
+            sphere_terms(tile[i], o, d, a, h, ncc, disc);
+            accept_exact(h, disc, a, t_min, base + (int)i, b);
+        }
+    }
+    c.n = 0u;
+}
+
+// Scan `count` (a multiple of RT_SCAN_UNROLL) spheres staged in LDS; every lane of the wavefront reads
+// the same float4 per step.  13 VALU operations per sphere and lane: the 11 of sphere_terms plus a
+// cheap superset test of "can this sphere be hit": a root in (t_min, ..) with t_min >= 0 needs
+// disc >= 0 and (h > 0 or the origin inside the sphere, ncc > 0), so a lane lists the sphere when the
+// sign bit of ((h & ncc) | disc) is clear.  The exact test (sqrt, two divides, ~60 operations) then
+// runs once per listed sphere with the lanes' lists side by side, instead of once per sphere of the
+// scan with one or two lanes active.  The closest hit does not depend on when a sphere is tested:
+// the accepted root of a sphere is its first root beyond t_min, if below the bound, whatever the bound.
 RT_DEV void scan_tile(const float4* __restrict__ tile, uint32_t count, int base,
-                      V3 o, V3 d, float a, float t_min, Best& b) {
+                      V3 o, V3 d, float a, float t_min, Best& b, Cand& c) {
     for (uint32_t i = 0; i < count; i += RT_SCAN_UNROLL) {
         float4 s[RT_SCAN_UNROLL];
 #pragma unroll
         for (uint32_t u = 0; u < RT_SCAN_UNROLL; u++) s[u] = tile[i + u];
 #pragma unroll
         for (uint32_t u = 0; u < RT_SCAN_UNROLL; u++) {
-            float ocx = s[u].x - o.x, ocy = s[u].y - o.y, ocz = s[u].z - o.z;
-            float h = fmaf(d.z, ocz, fmaf(d.y, ocy, d.x * ocx));
-            float ncc = fmaf(-ocz, ocz, fmaf(-ocy, ocy, fmaf(-ocx, ocx, s[u].w)));
-            float disc = fmaf(h, h, a * ncc);
+            float h, ncc, disc;
+            sphere_terms(s[u], o, d, a, h, ncc, disc);
             int key = (__float_as_int(h) & __float_as_int(ncc)) | __float_as_int(disc);
-            if (key >= 0) accept_exact(h, disc, a, t_min, base + (int)(i + u), b);
+            if (key >= 0) {
+                c.col[c.n * 64u] = (uint16_t)(i + u);
+                c.n++;
+            }
         }
+        if (__ballot(c.n > RT_CAND_CAP - RT_SCAN_UNROLL) != 0ull) drain(tile, base, c, o, d, a, t_min, b);
     }
+    drain(tile, base, c, o, d, a, t_min, b);
 }
 
 // ---------------------------------------------------------------- shading
@@ -243,7 +275,17 @@ RT_DEV void stage_tile(float4* tile, const float4* __restrict__ geom, uint32_t f
     for (uint32_t i = threadIdx.x; i < count; i += blockDim.x) tile[i] = geom[first + i];
 }
 
+// Dynamic LDS: [sphere tile: min(n_padded, RT_TILE_SPHERES) float4][candidate lists: waves x RT_CAND_CAP x 64 u16]
 extern __shared__ float4 rt_lds_tile[];
+
+RT_DEV Cand cand_list(const RtLaunch& L) {
+    uint32_t tile_spheres = L.n_padded < RT_TILE_SPHERES ? L.n_padded : RT_TILE_SPHERES;
+    uint16_t* base = reinterpret_cast<uint16_t*>(rt_lds_tile + tile_spheres);
+    Cand c;
+    c.col = base + (threadIdx.x >> 6) * (RT_CAND_CAP * 64u) + (threadIdx.x & 63u);
+    c.n = 0u;
+    return c;
+}
 
 // ---------------------------------------------------------------- render
 // MULTI = false: the whole (padded) sphere list fits the LDS tile; staged once, after which every
@@ -271,6 +313,7 @@ RT_DEV void render_body(const Scene& sc, uint32_t* __restrict__ rgba, float4* __
         __syncthreads();
     }
 
+    Cand cand = cand_list(L);
     float band = 0.0f;
     if (flags & RT_FLAG_BAND_ALBEDO) {                           // lib.rs:225-226
         uint32_t gi = L.width / 5u;
@@ -302,10 +345,10 @@ RT_DEV void render_body(const Scene& sc, uint32_t* __restrict__ rgba, float4* __
                 if (first) __syncthreads();                      // previous tile fully scanned
                 stage_tile(tile, sc.geom, first, count);
                 __syncthreads();
-                if (active) scan_tile(tile, count, (int)first, o, d, a, L.t_min, b);
+                if (active) scan_tile(tile, count, (int)first, o, d, a, L.t_min, b, cand);
             }
         } else {
-            if (active) scan_tile(tile, L.n_padded, 0, o, d, a, L.t_min, b);
+            if (active) scan_tile(tile, L.n_padded, 0, o, d, a, L.t_min, b, cand);
         }
         if (active) {
             nseg++;
@@ -392,13 +435,14 @@ rt_primary_hits(const float4* geom, int32_t* hits, RtCamera cam, RtLaunch L) {
     Best b;
     b.t = L.t_max;
     b.idx = -1;
+    Cand cand = cand_list(L);
     for (uint32_t first = 0u; first < L.n_padded; first += RT_TILE_SPHERES) {
         uint32_t count = L.n_padded - first;
         if (count > RT_TILE_SPHERES) count = RT_TILE_SPHERES;
         if (first) __syncthreads();
         stage_tile(tile, geom, first, count);
         __syncthreads();
-        if (valid) scan_tile(tile, count, (int)first, o, d, a, L.t_min, b);
+        if (valid) scan_tile(tile, count, (int)first, o, d, a, L.t_min, b, cand);
     }
     if (valid) hits[(size_t)ly * L.width + x] = b.idx;
 }
