@@ -47,8 +47,8 @@ const char *rt_last_error(const rt_ctx *ctx);
  * the reference compiles at run time with NVRTC, here the object is built by hipcc --genco. */
 int rt_load_module(rt_ctx *ctx, const void *image, size_t size);
 
-/* Uploads the sphere list: AoS host spheres -> device float4 arrays (geometry {c, r*r}; surface
- * {radius, fuzz|ior, material}; albedo).  Stands for the scene the reference builds inside its kernel
+/* Uploads the sphere list: AoS host spheres -> device arrays (scan data {c, r*r} packed two spheres per
+ * float4 pair; shading data {c, radius}, {albedo, fuzz|ior}; material tags).  Stands for the scene the reference builds inside its kernel
  * (gpu-implementation/src/cuda/ray.cu:94-106) and for the `world: &[T]` argument of Camera::render
  * (cpu-implementation/src/lib.rs:221). */
 int rt_upload_scene(rt_ctx *ctx, const RtSphere *spheres, uint32_t n);
@@ -86,6 +86,11 @@ int rt_show_random(rt_ctx *ctx, uint32_t width, uint32_t height, uint64_t seed, 
 
 /* Milliseconds the last render kernel took on the GPU (hipEvent pair around the launch). */
 float rt_last_kernel_ms(const rt_ctx *ctx);
+
+/* Diagnostic: the 8 counters of the last render that asked for rays_out.  out[0] = ray segments; slots 1..7 are
+ * loop-trip counts that only a code object built with -DRT_STATS fills (scan passes, candidates listed,
+ * exact-test rounds, decode rounds, unit-vector rounds, drain calls, reserved).  No counterpart in the reference. */
+int rt_debug_counters(rt_ctx *ctx, uint64_t out[8]);
 
 /* Name and compute-unit count of the context's GPU. */
 int rt_device_info(const rt_ctx *ctx, char *name, size_t name_size, int *compute_units, int *clock_khz);

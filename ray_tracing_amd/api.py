@@ -252,6 +252,11 @@ class HipWorld:
         self._check(self._lib.rt_show_random(self._ctx, width, height, seed, int(norm), _ffi.ptr(out)))
         return out
 
+    def debug_counters(self):
+        out = (C.c_uint64 * 8)()
+        self._check(self._lib.rt_debug_counters(self._ctx, C.byref(out)))
+        return list(out)
+
     def device_info(self):
         name = C.create_string_buffer(600)
         cus, khz = C.c_int(0), C.c_int(0)

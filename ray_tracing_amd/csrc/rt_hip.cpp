@@ -33,7 +33,7 @@ struct rt_ctx {
     hipModule_t module = nullptr;
     hipFunction_t f_render = nullptr, f_render_stream = nullptr, f_hits = nullptr, f_random = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    void *d_geom = nullptr, *d_surf = nullptr, *d_albedo = nullptr;
+    void *d_geom = nullptr, *d_shade = nullptr, *d_mat = nullptr;
     uint32_t n_spheres = 0, n_padded = 0;
     bool have_scene = false;
     void *d_rgba = nullptr, *d_linear = nullptr, *d_hits = nullptr, *d_counter = nullptr;
@@ -156,9 +156,9 @@ int launch_render(rt_ctx* c, const RtCamera* cam, const RtParams* p, RtLaunch L,
     unsigned grid, block;
     launch_geometry(p, L, &grid, &block);
     void* d_count = rays_out ? c->d_counter : nullptr;
-    if (rays_out) RT_HIP(c, hipMemsetAsync(c->d_counter, 0, 8, c->stream));
+    if (rays_out) RT_HIP(c, hipMemsetAsync(c->d_counter, 0, 64, c->stream));
     RtCamera cam_copy = *cam;
-    void* args[] = {&c->d_geom, &c->d_surf, &c->d_albedo, &d_rgba, &d_linear, &d_count, &cam_copy, &L};
+    void* args[] = {&c->d_geom, &c->d_shade, &c->d_mat, &d_rgba, &d_linear, &d_count, &cam_copy, &L};
     hipFunction_t f = (c->n_padded <= RT_TILE_SPHERES) ? c->f_render : c->f_render_stream;
     RT_HIP(c, hipEventRecord(c->ev0, c->stream));
     if (grid > 0)
@@ -207,7 +207,7 @@ int rt_create(int device, rt_ctx** out) {
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail(hip_fail(c, e, "hipStreamCreate"));
     if ((e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess)
         return bail(hip_fail(c, e, "hipEventCreate"));
-    if ((e = hipMalloc(&c->d_counter, 8)) != hipSuccess) return bail(hip_fail(c, e, "hipMalloc"));
+    if ((e = hipMalloc(&c->d_counter, 64)) != hipSuccess) return bail(hip_fail(c, e, "hipMalloc"));
     if ((rc = load_image(c, rt_embedded_hsaco)) != 0) return bail(rc);
     *out = c;
     return 0;
@@ -217,7 +217,7 @@ void rt_destroy(rt_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    void* bufs[] = {c->d_geom, c->d_surf, c->d_albedo, c->d_rgba, c->d_linear, c->d_hits, c->d_counter};
+    void* bufs[] = {c->d_geom, c->d_shade, c->d_mat, c->d_rgba, c->d_linear, c->d_hits, c->d_counter};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -241,42 +241,43 @@ int rt_upload_scene(rt_ctx* c, const RtSphere* spheres, uint32_t n) {
     RT_HIP(c, hipSetDevice(c->device));
     uint32_t n_padded = ((n + RT_SCAN_UNROLL - 1u) / RT_SCAN_UNROLL) * RT_SCAN_UNROLL;
     if (n_padded == 0) n_padded = RT_SCAN_UNROLL;
-    std::vector<float> geom((size_t)n_padded * 4), surf((size_t)n_padded * 4), alb((size_t)n_padded * 4);
+    // geom: scan layout, two spheres per pair of float4: {cx0,cx1,cy0,cy1} {cz0,cz1,rr0,rr1}
+    // shade: {cx,cy,cz,radius} {albedo rgb, fuzz|ior} per sphere;  mat: material tag per sphere
+    std::vector<float> geom((size_t)n_padded * 4), shade((size_t)n_padded * 8);
+    std::vector<uint32_t> mat(n_padded);
     for (uint32_t i = 0; i < n_padded; i++) {
-        float* g = &geom[4 * (size_t)i];
-        float* s = &surf[4 * (size_t)i];
-        float* a = &alb[4 * (size_t)i];
+        float* g = &geom[(size_t)(i >> 1) * 8 + (i & 1u)];
+        float* s = &shade[8 * (size_t)i];
         if (i < n) {
             const RtSphere& sp = spheres[i];
             if (sp.material < RT_MAT_DIFFUSE || sp.material > RT_MAT_DIELECTRIC)
                 return fail(c, RT_ERR_INVALID, "unknown material tag in sphere " + std::to_string(i));
-            g[0] = sp.center[0]; g[1] = sp.center[1]; g[2] = sp.center[2];
-            g[3] = sp.radius * sp.radius;            // radius*radius, library.cu:203 / lib.rs:101
-            s[0] = sp.radius;
+            g[0] = sp.center[0]; g[2] = sp.center[1]; g[4] = sp.center[2];
+            g[6] = sp.radius * sp.radius;            // radius*radius, library.cu:203 / lib.rs:101
             float param = sp.param;
             if (sp.material == RT_MAT_REFLECT) param = param < 1.0f ? param : 1.0f;   // library.cu:144
-            s[1] = param;
-            std::memcpy(&s[2], &sp.material, 4);
-            s[3] = 0.0f;
-            a[0] = sp.albedo[0]; a[1] = sp.albedo[1]; a[2] = sp.albedo[2]; a[3] = 0.0f;
+            s[0] = sp.center[0]; s[1] = sp.center[1]; s[2] = sp.center[2]; s[3] = sp.radius;
+            s[4] = sp.albedo[0]; s[5] = sp.albedo[1]; s[6] = sp.albedo[2]; s[7] = param;
+            mat[i] = sp.material;
         } else {
             // padding up to the scan's unroll factor: r*r = -inf makes the discriminant -inf, never a hit
-            g[0] = g[1] = g[2] = 0.0f; g[3] = -INFINITY;
-            s[0] = 1.0f; s[1] = 0.0f; s[2] = 0.0f; s[3] = 0.0f;
-            a[0] = a[1] = a[2] = a[3] = 0.0f;
+            g[0] = g[2] = g[4] = 0.0f; g[6] = -INFINITY;
+            s[0] = s[1] = s[2] = 0.0f; s[3] = 1.0f;
+            s[4] = s[5] = s[6] = s[7] = 0.0f;
+            mat[i] = RT_MAT_DIFFUSE;
         }
     }
     size_t bytes = (size_t)n_padded * 16u;
     if (c->d_geom) { RT_HIP(c, hipFree(c->d_geom)); c->d_geom = nullptr; }
-    if (c->d_surf) { RT_HIP(c, hipFree(c->d_surf)); c->d_surf = nullptr; }
-    if (c->d_albedo) { RT_HIP(c, hipFree(c->d_albedo)); c->d_albedo = nullptr; }
+    if (c->d_shade) { RT_HIP(c, hipFree(c->d_shade)); c->d_shade = nullptr; }
+    if (c->d_mat) { RT_HIP(c, hipFree(c->d_mat)); c->d_mat = nullptr; }
     c->have_scene = false;
     RT_HIP(c, hipMalloc(&c->d_geom, bytes));
-    RT_HIP(c, hipMalloc(&c->d_surf, bytes));
-    RT_HIP(c, hipMalloc(&c->d_albedo, bytes));
+    RT_HIP(c, hipMalloc(&c->d_shade, 2 * bytes));
+    RT_HIP(c, hipMalloc(&c->d_mat, (size_t)n_padded * 4u));
     RT_HIP(c, hipMemcpy(c->d_geom, geom.data(), bytes, hipMemcpyHostToDevice));
-    RT_HIP(c, hipMemcpy(c->d_surf, surf.data(), bytes, hipMemcpyHostToDevice));
-    RT_HIP(c, hipMemcpy(c->d_albedo, alb.data(), bytes, hipMemcpyHostToDevice));
+    RT_HIP(c, hipMemcpy(c->d_shade, shade.data(), 2 * bytes, hipMemcpyHostToDevice));
+    RT_HIP(c, hipMemcpy(c->d_mat, mat.data(), (size_t)n_padded * 4u, hipMemcpyHostToDevice));
     c->n_spheres = n;
     c->n_padded = n_padded;
     c->have_scene = true;
@@ -352,6 +353,13 @@ int rt_show_random(rt_ctx* c, uint32_t width, uint32_t height, uint64_t seed, in
 }
 
 float rt_last_kernel_ms(const rt_ctx* c) { return c ? c->last_ms : 0.0f; }
+
+int rt_debug_counters(rt_ctx* c, uint64_t out[8]) {
+    if (!c || !out) return RT_ERR_INVALID;
+    RT_HIP(c, hipSetDevice(c->device));
+    RT_HIP(c, hipMemcpy(out, c->d_counter, 64, hipMemcpyDeviceToHost));
+    return 0;
+}
 
 int rt_device_info(const rt_ctx* c, char* name, size_t name_size, int* compute_units, int* clock_khz) {
     if (!c) return RT_ERR_INVALID;

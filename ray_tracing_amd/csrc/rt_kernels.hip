@@ -25,6 +25,27 @@ RT_DEV float vdot(V3 a, V3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x))
 RT_DEV V3 vunit(V3 v) { float inv = 1.0f / sqrtf(vdot(v, v)); return vscale(v, inv); }
 RT_DEV V3 ld3(const float* p) { return v3(p[0], p[1], p[2]); }
 
+// ---------------------------------------------------------------- diagnostics
+// Built with -DRT_STATS the kernels also count loop trips, summed over the launch.  Slots 1..7 of the
+// counter buffer: [1] scan passes per wavefront, [2] candidates listed (per lane), [3] exact-test rounds
+// per wavefront, [4] decode rounds per wavefront, [5] unit-vector tries per lane, [6] drain calls per
+// wavefront, [7] unit-vector rounds per wavefront.  Without RT_STATS the calls compile to nothing.
+struct Stats {
+#ifdef RT_STATS
+    uint32_t v[8];
+    RT_DEV Stats() { for (int i = 0; i < 8; i++) v[i] = 0u; }
+    RT_DEV void add(int which, uint32_t n) { v[which] += n; }
+    // counted once per wavefront: by the first lane that is active at the call
+    RT_DEV void wave(int which) {
+        unsigned long long m = __ballot(1);
+        if ((uint32_t)(__ffsll((long long)m) - 1) == (threadIdx.x & 63u)) v[which] += 1u;
+    }
+#else
+    RT_DEV void add(int, uint32_t) {}
+    RT_DEV void wave(int) {}
+#endif
+};
+
 // ---------------------------------------------------------------- RNG
 // PCG32 XSH-RR (library.cu:7-16), one stream per (seed, pixel, sample, k): k = 0 feeds the camera
 // jitter, k = j+1 the scatter that ends path segment j.  Seeding is pcg32_srandom_r(key, pixel) with
@@ -55,10 +76,12 @@ RT_DEV float rand01(Rng& g) { return (float)(pcg_next(g) >> 8) * 0x1p-24f; }
 
 // Rejection in [-1,1)^3, accept p.p <= 1, normalise (lib.rs:31-47); at most 20 tries, then (1,0,0)
 // (library.cu:25-31).
-RT_DEV V3 random_unit_vector(Rng& g) {
+RT_DEV V3 random_unit_vector(Rng& g, Stats& st) {
     V3 r = v3(1.0f, 0.0f, 0.0f);
     bool done = false;
     for (int i = 0; i < 20 && !done; i++) {
+        st.add(5, 1u);
+        st.wave(7);
         float x = fmaf(2.0f, rand01(g), -1.0f);
         float y = fmaf(2.0f, rand01(g), -1.0f);
         float z = fmaf(2.0f, rand01(g), -1.0f);
@@ -87,74 +110,129 @@ RT_DEV void accept_exact(float h, float disc, float a, float t_min, int idx, Bes
 
 // The three per-sphere terms, in the checker's op order:
 //   oc = c - o; h = d.oc; ncc = r*r - oc.oc (accumulated from r*r down); disc = h*h + a*ncc
-RT_DEV void sphere_terms(float4 s, V3 o, V3 d, float a, float& h, float& ncc, float& disc) {
-    float ocx = s.x - o.x, ocy = s.y - o.y, ocz = s.z - o.z;
+RT_DEV void sphere_terms(float cx, float cy, float cz, float rr, V3 o, V3 d, float a, float& h, float& ncc, float& disc) {
+    float ocx = cx - o.x, ocy = cy - o.y, ocz = cz - o.z;
     h = fmaf(d.z, ocz, fmaf(d.y, ocy, d.x * ocx));
-    ncc = fmaf(-ocz, ocz, fmaf(-ocy, ocy, fmaf(-ocx, ocx, s.w)));
+    ncc = fmaf(-ocz, ocz, fmaf(-ocy, ocy, fmaf(-ocx, ocx, rr)));
     disc = fmaf(h, h, a * ncc);
+}
+
+// LDS sphere tile, two spheres per pair of float4 so that packed-fp32 operations take one sphere in each
+// half of a register pair:   tile[2p] = {cx0, cx1, cy0, cy1}   tile[2p+1] = {cz0, cz1, rr0, rr1}
+RT_DEV void tile_sphere(const float4* __restrict__ tile, uint32_t i, float& cx, float& cy, float& cz, float& rr) {
+    const float* f = reinterpret_cast<const float*>(tile) + (i >> 1) * 8u + (i & 1u);
+    cx = f[0]; cy = f[2]; cz = f[4]; rr = f[6];
 }
 
 // Per-lane list of candidate spheres of the tile being scanned, kept in LDS as a column of a
 // [RT_CAND_CAP][64] u16 array per wavefront (lane l owns column l, so pushes never conflict).
 struct Cand { uint16_t* col; uint32_t n; };
 
+RT_DEV void push(Cand& c, uint32_t idx) {
+    c.col[c.n * 64u] = (uint16_t)idx;
+    c.n++;
+}
+
 // Runs the exact test on every listed sphere, in list (= index) order.  Lanes with shorter lists idle
 // for the extra rounds; the terms are recomputed from the staged sphere, bit for bit those of the scan.
-RT_DEV void drain(const float4* __restrict__ tile, int base, Cand& c, V3 o, V3 d, float a, float t_min, Best& b) {
+RT_DEV void drain(const float4* __restrict__ tile, int base, Cand& c, V3 o, V3 d, float a, float t_min, Best& b, Stats& st) {
+    st.wave(6);
     for (uint32_t k = 0; __ballot(k < c.n) != 0ull; k++) {
+        st.wave(3);
         if (k < c.n) {
             uint32_t i = c.col[k * 64u];
-            float h, ncc, disc;
-            sphere_terms(tile[i], o, d, a, h, ncc, disc);
+            float cx, cy, cz, rr, h, ncc, disc;
+            tile_sphere(tile, i, cx, cy, cz, rr);
+            sphere_terms(cx, cy, cz, rr, o, d, a, h, ncc, disc);
             accept_exact(h, disc, a, t_min, base + (int)i, b);
         }
     }
     c.n = 0u;
 }
 
+#ifndef RT_VARIANT
+#define RT_VARIANT 2
+#endif
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+RT_DEV f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+
 // Scan `count` (a multiple of RT_SCAN_UNROLL) spheres staged in LDS; every lane of the wavefront reads
-// the same float4 per step.  13 VALU operations per sphere and lane: the 11 of sphere_terms plus a
-// cheap superset test of "can this sphere be hit": a root in (t_min, ..) with t_min >= 0 needs
-// disc >= 0 and (h > 0 or the origin inside the sphere, ncc > 0), so a lane lists the sphere when the
-// sign bit of ((h & ncc) | disc) is clear.  The exact test (sqrt, two divides, ~60 operations) then
-// runs once per listed sphere with the lanes' lists side by side, instead of once per sphere of the
-// scan with one or two lanes active.  The closest hit does not depend on when a sphere is tested:
-// the accepted root of a sphere is its first root beyond t_min, if below the bound, whatever the bound.
+// the same two float4 per sphere pair.  Per pair and lane: the 11 operations of sphere_terms as packed
+// fp32 instructions (one sphere per register half; v_pk_add/mul/fma are IEEE per half, so the values
+// are those of the scalar form), then per sphere a cheap superset test of "can this sphere be hit":
+// a root in (t_min, ..) with t_min >= 0 needs disc >= 0 and (h > 0 or the origin inside the sphere,
+// ncc > 0), so the sphere is a candidate for the lane when the sign bit of key = ((h & ncc) | disc) is
+// clear.  The sign bits of up to 32 consecutive spheres are shifted into one register per lane
+// (v_alignbit: miss = miss << 1 | key >> 31), so the scan itself has no branch and no compare.  After
+// each block the (few) clear bits are turned into entries of the lane's candidate list, and the exact
+// test (sqrt, two divides, ~60 operations) runs once per listed sphere with the lanes' lists side by
+// side, instead of once per sphere of the scan with one or two lanes active.  The closest hit does
+// not depend on when a sphere is tested: the accepted root of a sphere is its first root beyond
+// t_min, if below the bound, whatever the bound.
 RT_DEV void scan_tile(const float4* __restrict__ tile, uint32_t count, int base,
-                      V3 o, V3 d, float a, float t_min, Best& b, Cand& c) {
-    for (uint32_t i = 0; i < count; i += RT_SCAN_UNROLL) {
-        float4 s[RT_SCAN_UNROLL];
+                      V3 o, V3 d, float a, float t_min, Best& b, Cand& c, Stats& st) {
+    st.wave(1);
+#if RT_VARIANT == 3
+    const f2 ox = {o.x, o.x}, oy = {o.y, o.y}, oz = {o.z, o.z};
+    const f2 dx = {d.x, d.x}, dy = {d.y, d.y}, dz = {d.z, d.z}, a2 = {a, a};
+#endif
+    for (uint32_t blk = 0; blk < count; blk += 32u) {
+        const uint32_t k = (count - blk) < 32u ? (count - blk) : 32u;   // spheres in this block, multiple of 8
+        uint32_t miss = 0u;                                            // bit j set: sphere blk + (k-1-j) cannot be hit
+        for (uint32_t i = 0; i < k; i += RT_SCAN_UNROLL) {
+            float4 s[RT_SCAN_UNROLL];
 #pragma unroll
-        for (uint32_t u = 0; u < RT_SCAN_UNROLL; u++) s[u] = tile[i + u];
+            for (uint32_t u = 0; u < RT_SCAN_UNROLL; u++) s[u] = tile[blk + i + u];
 #pragma unroll
-        for (uint32_t u = 0; u < RT_SCAN_UNROLL; u++) {
-            float h, ncc, disc;
-            sphere_terms(s[u], o, d, a, h, ncc, disc);
-            int key = (__float_as_int(h) & __float_as_int(ncc)) | __float_as_int(disc);
-            if (key >= 0) {
-                c.col[c.n * 64u] = (uint16_t)(i + u);
-                c.n++;
+            for (uint32_t u = 0; u < RT_SCAN_UNROLL; u += 2) {
+                const float4 A = s[u], B = s[u + 1];
+#if RT_VARIANT == 3
+                const f2 ocx = f2{A.x, A.y} - ox, ocy = f2{A.z, A.w} - oy, ocz = f2{B.x, B.y} - oz;
+                const f2 h = pk_fma(dz, ocz, pk_fma(dy, ocy, dx * ocx));
+                const f2 ncc = pk_fma(-ocz, ocz, pk_fma(-ocy, ocy, pk_fma(-ocx, ocx, f2{B.z, B.w})));
+                const f2 disc = pk_fma(h, h, a2 * ncc);
+                const float h0 = h.x, h1 = h.y, n0 = ncc.x, n1 = ncc.y, q0 = disc.x, q1 = disc.y;
+#else
+                float h0, n0, q0, h1, n1, q1;
+                sphere_terms(A.x, A.z, B.x, B.z, o, d, a, h0, n0, q0);
+                sphere_terms(A.y, A.w, B.y, B.w, o, d, a, h1, n1, q1);
+#endif
+                uint32_t key0 = (__float_as_uint(h0) & __float_as_uint(n0)) | __float_as_uint(q0);
+                uint32_t key1 = (__float_as_uint(h1) & __float_as_uint(n1)) | __float_as_uint(q1);
+                miss = __builtin_amdgcn_alignbit(miss, key0, 31u);
+                miss = __builtin_amdgcn_alignbit(miss, key1, 31u);
             }
         }
-        if (__ballot(c.n > RT_CAND_CAP - RT_SCAN_UNROLL) != 0ull) drain(tile, base, c, o, d, a, t_min, b);
+        uint32_t bits = ~miss & (k == 32u ? 0xffffffffu : ((1u << k) - 1u));
+        while (__ballot(bits != 0u) != 0ull) {
+            st.wave(4);
+            if (bits != 0u) {
+                st.add(2, 1u);
+                uint32_t pos = 31u - (uint32_t)__clz((int)bits);        // highest bit = lowest sphere index first
+                push(c, blk + (k - 1u - pos));
+                bits &= ~(1u << pos);
+            }
+            if (__ballot(c.n >= RT_CAND_CAP) != 0ull) drain(tile, base, c, o, d, a, t_min, b, st);
+        }
     }
-    drain(tile, base, c, o, d, a, t_min, b);
+    drain(tile, base, c, o, d, a, t_min, b, st);
 }
 
 // ---------------------------------------------------------------- shading
 struct Scene {
-    const float4* __restrict__ geom;    // {cx, cy, cz, r*r}, n_padded entries
-    const float4* __restrict__ surf;    // {radius, param, material bits, 0}
-    const float4* __restrict__ albedo;  // {r, g, b, 0}
+    const float4* __restrict__ geom;    // scan data in the tile layout above, n_padded float4
+    const float4* __restrict__ shade;   // per sphere two float4: {cx, cy, cz, radius}, {albedo r, g, b, fuzz | ior}
+    const uint32_t* __restrict__ mat;   // material tag per sphere
 };
 
 struct HitInfo { V3 p, n; bool front; };
 
 // Hit record of the closest sphere: point, normal facing the ray (library.cu:220-225, lib.rs:118-122).
-RT_DEV HitInfo finish_hit(const Scene& sc, int idx, float t, V3 o, V3 d, float radius, uint32_t flags) {
+RT_DEV HitInfo finish_hit(float4 cr, float t, V3 o, V3 d, uint32_t flags) {
     HitInfo h;
-    float4 g = sc.geom[idx];
-    V3 c = v3(g.x, g.y, g.z);
+    V3 c = v3(cr.x, cr.y, cr.z);
+    const float radius = cr.w;
     h.p = v3(fmaf(d.x, t, o.x), fmaf(d.y, t, o.y), fmaf(d.z, t, o.z));
     V3 pc = vsub(h.p, c);
     V3 n = v3(pc.x / radius, pc.y / radius, pc.z / radius);
@@ -177,9 +255,9 @@ RT_DEV V3 sky(V3 d, float blend) {
 
 // Material::scatter (library.cu:131-149,175-183) plus the book's dielectric.  Draw order: one uniform
 // (dielectric choice), then the unit-vector rejection triples.
-RT_DEV V3 scatter(uint32_t mat, float param, V3 d, const HitInfo& h, Rng& g, uint32_t flags) {
+RT_DEV V3 scatter(uint32_t mat, float param, V3 d, const HitInfo& h, Rng& g, uint32_t flags, Stats& st) {
     float u_choice = rand01(g);
-    V3 ru = random_unit_vector(g);
+    V3 ru = random_unit_vector(g, st);
     V3 n = h.n;
     V3 out;
     if ((flags & RT_FLAG_BAND_ALBEDO) || mat == RT_MAT_DIFFUSE) {
@@ -314,6 +392,7 @@ RT_DEV void render_body(const Scene& sc, uint32_t* __restrict__ rgba, float4* __
     }
 
     Cand cand = cand_list(L);
+    Stats st;
     float band = 0.0f;
     if (flags & RT_FLAG_BAND_ALBEDO) {                           // lib.rs:225-226
         uint32_t gi = L.width / 5u;
@@ -345,27 +424,27 @@ RT_DEV void render_body(const Scene& sc, uint32_t* __restrict__ rgba, float4* __
                 if (first) __syncthreads();                      // previous tile fully scanned
                 stage_tile(tile, sc.geom, first, count);
                 __syncthreads();
-                if (active) scan_tile(tile, count, (int)first, o, d, a, L.t_min, b, cand);
+                if (active) scan_tile(tile, count, (int)first, o, d, a, L.t_min, b, cand, st);
             }
         } else {
-            if (active) scan_tile(tile, L.n_padded, 0, o, d, a, L.t_min, b, cand);
+            if (active) scan_tile(tile, L.n_padded, 0, o, d, a, L.t_min, b, cand, st);
         }
         if (active) {
             nseg++;
             bool path_done;
             V3 color;
             if (b.idx >= 0) {                                    // ray.cu:35-40
-                float4 sf = sc.surf[b.idx];
-                uint32_t mat = (uint32_t)__float_as_int(sf.z);
-                HitInfo h = finish_hit(sc, b.idx, b.t, o, d, sf.x, flags);
+                const float4 cr = sc.shade[2 * b.idx];
+                const float4 al = sc.shade[2 * b.idx + 1];
+                const uint32_t mat = sc.mat[b.idx];
+                HitInfo h = finish_hit(cr, b.t, o, d, flags);
                 Rng g = stream_init(seed, pixel, s, seg + 1u);
-                V3 nd = scatter(mat, sf.y, d, h, g, flags);
+                V3 nd = scatter(mat, al.w, d, h, g, flags, st);
                 o = h.p;
                 d = nd;
                 if (flags & RT_FLAG_BAND_ALBEDO) {
                     nb++;
                 } else {
-                    float4 al = sc.albedo[b.idx];
                     thr = v3(thr.x * al.x, thr.y * al.y, thr.z * al.z);   // ray.cu:37
                 }
                 seg++;
@@ -403,20 +482,27 @@ RT_DEV void render_body(const Scene& sc, uint32_t* __restrict__ rgba, float4* __
         // one 64-bit atomic per wavefront
         for (int off = 32; off > 0; off >>= 1) nseg += __shfl_xor(nseg, off);
         if (lane == 0u && nseg) atomicAdd(segments, nseg);
+#ifdef RT_STATS
+        for (int w = 1; w < 8; w++) {
+            unsigned long long x = st.v[w];
+            for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
+            if (lane == 0u && x) atomicAdd(segments + w, x);
+        }
+#endif
     }
 }
 
 extern "C" __global__ void __launch_bounds__(1024)
-rt_render(const float4* geom, const float4* surf, const float4* albedo, uint32_t* rgba, float4* linear,
+rt_render(const float4* geom, const float4* shade, const uint32_t* mat, uint32_t* rgba, float4* linear,
           unsigned long long* segments, RtCamera cam, RtLaunch L) {
-    Scene sc = {geom, surf, albedo};
+    Scene sc = {geom, shade, mat};
     render_body<false>(sc, rgba, linear, segments, cam, L);
 }
 
 extern "C" __global__ void __launch_bounds__(1024)
-rt_render_stream(const float4* geom, const float4* surf, const float4* albedo, uint32_t* rgba, float4* linear,
+rt_render_stream(const float4* geom, const float4* shade, const uint32_t* mat, uint32_t* rgba, float4* linear,
                  unsigned long long* segments, RtCamera cam, RtLaunch L) {
-    Scene sc = {geom, surf, albedo};
+    Scene sc = {geom, shade, mat};
     render_body<true>(sc, rgba, linear, segments, cam, L);
 }
 
@@ -436,13 +522,14 @@ rt_primary_hits(const float4* geom, int32_t* hits, RtCamera cam, RtLaunch L) {
     b.t = L.t_max;
     b.idx = -1;
     Cand cand = cand_list(L);
+    Stats st;
     for (uint32_t first = 0u; first < L.n_padded; first += RT_TILE_SPHERES) {
         uint32_t count = L.n_padded - first;
         if (count > RT_TILE_SPHERES) count = RT_TILE_SPHERES;
         if (first) __syncthreads();
         stage_tile(tile, geom, first, count);
         __syncthreads();
-        if (valid) scan_tile(tile, count, (int)first, o, d, a, L.t_min, b, cand);
+        if (valid) scan_tile(tile, count, (int)first, o, d, a, L.t_min, b, cand, st);
     }
     if (valid) hits[(size_t)ly * L.width + x] = b.idx;
 }
@@ -455,7 +542,8 @@ rt_show_random(uint32_t* rgba, uint32_t n_pixels, uint32_t seed_lo, uint32_t see
     Rng g = stream_init(((uint64_t)seed_hi << 32) | seed_lo, p, 0u, 0u);
     V3 c;
     if (norm) {
-        c = random_unit_vector(g);
+        Stats st;
+        c = random_unit_vector(g, st);
     } else {
         c.x = rand01(g); c.y = rand01(g); c.z = rand01(g);
     }

@@ -18,7 +18,10 @@ else:
     sp = rt.scene_cpu_default(); cam = rt.Camera.new_cpu(16 / 9, width)
 p = rt.cpu_params(spp, depth, block_dim=block) if scene == "cpu" else rt.DeviceGUI(samples_per_pixel=spp, max_depth=depth, seed=1, block_dim=block)
 w = rt.HipWorld(0, sp)
-print(w.device_info())
+hs = os.environ.get("RT_HSACO")
+if hs:
+    w.load_module(open(hs, "rb").read())
+print(w.device_info(), hs)
 n = len(sp)
 for it in range(3):
     t0 = time.time()
@@ -28,4 +31,5 @@ for it in range(3):
     flops = r["rays"] * (18 * n + 64)
     print(f"{scene} {cam.image_width}x{cam.image_height} spp={spp} depth={depth} n={n}: rays={r['rays']} "
           f"({r['rays'] / (cam.image_width * cam.image_height * spp):.2f}/sample) kernel {ms:.2f} ms wall {dt * 1e3:.1f} ms "
+          + (f"stats {w.debug_counters()} " if hs and "stats" in hs else "") +
           f"-> {r['rays'] / ms * 1e-3:.1f} Mrays/s, {flops / ms * 1e-9:.2f} TFLOP/s ({flops / ms * 1e-9 / 157.3 * 100:.1f}% of 157.3)", flush=True)
