@@ -27,9 +27,9 @@ typedef struct RtLaunch {
 } RtLaunch;
 
 #define RT_SCAN_UNROLL 8u
-// Spheres staged in LDS at a time: 4096 x 16 B = 64 KiB.  Scenes up to this size are staged once per
+// Spheres staged in LDS at a time: 2048 x 20 B = 40 KiB.  Scenes up to this size are staged once per
 // workgroup; larger ones are streamed through the same buffer tile by tile.
-#define RT_TILE_SPHERES 4096u
+#define RT_TILE_SPHERES 2048u
 // Candidate slots per lane (u16 each, in LDS); a wavefront drains its lists when a lane holds more than
 // RT_CAND_CAP - RT_SCAN_UNROLL, so a scan step can never overflow them.
 #define RT_CAND_CAP 24u

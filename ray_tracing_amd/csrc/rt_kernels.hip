@@ -95,9 +95,11 @@ RT_DEV V3 random_unit_vector(Rng& g, Stats& st) {
 struct Best { float t; int idx; };
 
 // Exact acceptance of Sphere::hit (library.cu:205-218, lib.rs:103-117) for one sphere against the
-// current upper bound.  Ties keep the lower index because the bound is strict.
-RT_DEV void accept_exact(float h, float disc, float a, float t_min, int idx, Best& b) {
-    if (disc >= 0.0f) {
+// current upper bound.  Ties keep the lower index because the bound is strict.  The first line skips
+// the square root and the divides where no root can qualify: with t_min >= 0, a root beyond t_min needs
+// h > 0 or the origin inside the sphere (ncc > 0); otherwise sqrt(disc) <= |h| and both roots are <= 0.
+RT_DEV void accept_exact(float h, float ncc, float disc, float a, float t_min, int idx, Best& b) {
+    if (disc >= 0.0f && (h > 0.0f || ncc > 0.0f)) {
         float s = sqrtf(disc);
         float root_a = (h - s) / a;
         float root_b = (h + s) / a;
@@ -117,12 +119,10 @@ RT_DEV void sphere_terms(float cx, float cy, float cz, float rr, V3 o, V3 d, flo
     disc = fmaf(h, h, a * ncc);
 }
 
-// LDS sphere tile, two spheres per pair of float4 so that packed-fp32 operations take one sphere in each
-// half of a register pair:   tile[2p] = {cx0, cx1, cy0, cy1}   tile[2p+1] = {cz0, cz1, rr0, rr1}
-RT_DEV void tile_sphere(const float4* __restrict__ tile, uint32_t i, float& cx, float& cy, float& cz, float& rr) {
-    const float* f = reinterpret_cast<const float*>(tile) + (i >> 1) * 8u + (i & 1u);
-    cx = f[0]; cy = f[2]; cz = f[4]; rr = f[6];
-}
+// LDS sphere tile of one workgroup:
+//   geo[i] = {cx, cy, cz, rr_f}   rr_f = r*r inflated by 2^-17 (scan filter only)
+//   rrx[i] = r*r                  exact, for the exact test
+struct Tile { const float4* geo; const float* rrx; };
 
 // Per-lane list of candidate spheres of the tile being scanned, kept in LDS as a column of a
 // [RT_CAND_CAP][64] u16 array per wavefront (lane l owns column l, so pushes never conflict).
@@ -134,48 +134,48 @@ RT_DEV void push(Cand& c, uint32_t idx) {
 }
 
 // Runs the exact test on every listed sphere, in list (= index) order.  Lanes with shorter lists idle
-// for the extra rounds; the terms are recomputed from the staged sphere, bit for bit those of the scan.
-RT_DEV void drain(const float4* __restrict__ tile, int base, Cand& c, V3 o, V3 d, float a, float t_min, Best& b, Stats& st) {
+// for the extra rounds.
+RT_DEV void drain(const Tile& tile, int base, Cand& c, V3 o, V3 d, float a, float t_min, Best& b, Stats& st) {
     st.wave(6);
     for (uint32_t k = 0; __ballot(k < c.n) != 0ull; k++) {
         st.wave(3);
         if (k < c.n) {
             uint32_t i = c.col[k * 64u];
-            float cx, cy, cz, rr, h, ncc, disc;
-            tile_sphere(tile, i, cx, cy, cz, rr);
-            sphere_terms(cx, cy, cz, rr, o, d, a, h, ncc, disc);
-            accept_exact(h, disc, a, t_min, base + (int)i, b);
+            float4 g = tile.geo[i];
+            float h, ncc, disc;
+            sphere_terms(g.x, g.y, g.z, tile.rrx[i], o, d, a, h, ncc, disc);
+            accept_exact(h, ncc, disc, a, t_min, base + (int)i, b);
         }
     }
     c.n = 0u;
 }
 
 #ifndef RT_VARIANT
-#define RT_VARIANT 2
+#define RT_VARIANT 4
 #endif
 
-typedef float f2 __attribute__((ext_vector_type(2)));
-RT_DEV f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
-
 // Scan `count` (a multiple of RT_SCAN_UNROLL) spheres staged in LDS; every lane of the wavefront reads
-// the same two float4 per sphere pair.  Per pair and lane: the 11 operations of sphere_terms as packed
-// fp32 instructions (one sphere per register half; v_pk_add/mul/fma are IEEE per half, so the values
-// are those of the scalar form), then per sphere a cheap superset test of "can this sphere be hit":
-// a root in (t_min, ..) with t_min >= 0 needs disc >= 0 and (h > 0 or the origin inside the sphere,
-// ncc > 0), so the sphere is a candidate for the lane when the sign bit of key = ((h & ncc) | disc) is
-// clear.  The sign bits of up to 32 consecutive spheres are shifted into one register per lane
-// (v_alignbit: miss = miss << 1 | key >> 31), so the scan itself has no branch and no compare.  After
-// each block the (few) clear bits are turned into entries of the lane's candidate list, and the exact
-// test (sqrt, two divides, ~60 operations) runs once per listed sphere with the lanes' lists side by
-// side, instead of once per sphere of the scan with one or two lanes active.  The closest hit does
-// not depend on when a sphere is tested: the accepted root of a sphere is its first root beyond
-// t_min, if below the bound, whatever the bound.
-RT_DEV void scan_tile(const float4* __restrict__ tile, uint32_t count, int base,
+// the same float4 per sphere.  The scan only has to list, per lane, a SUPERSET of the spheres the exact
+// test can accept; the exact test (sqrt, two divides, ~70 operations) then runs once per listed sphere
+// with the lanes' lists side by side (drain), instead of once per sphere of the scan with one or two
+// lanes active.  The closest hit does not depend on when a sphere is tested: the accepted root of a
+// sphere is its first root beyond t_min, if below the bound, whatever the bound.
+//
+// Filter, 10 VALU operations per sphere and lane (+1 to record the outcome):
+//   oc = c - o;  hf = uf.oc;  nf = rr_f - oc.oc;  q = hf*hf + nf;   candidate iff q >= 0
+// with uf = d * (1/sqrt(d.d)) * (1 + 2^-19) and rr_f = r*r * (1 + 2^-17).  q approximates disc/a of the
+// exact test; the two inflations exceed every rounding difference between q and disc/a (each is below
+// 34 * 2^-24 * oc.oc + 7 * 2^-24 * r*r for values in the normal range, see the derivation in the
+// design notes), so disc >= 0 implies q >= 0.  A NaN anywhere yields a candidate or a sphere the exact
+// test rejects as well.  The sign bits of q for up to 32 consecutive spheres are shifted into one
+// register per lane (v_alignbit: miss = miss << 1 | q >> 31), so the scan has no branch and no compare;
+// after each block the few clear bits become entries of the lane's candidate list.
+RT_DEV void scan_tile(const Tile& tile, uint32_t count, int base,
                       V3 o, V3 d, float a, float t_min, Best& b, Cand& c, Stats& st) {
     st.wave(1);
-#if RT_VARIANT == 3
-    const f2 ox = {o.x, o.x}, oy = {o.y, o.y}, oz = {o.z, o.z};
-    const f2 dx = {d.x, d.x}, dy = {d.y, d.y}, dz = {d.z, d.z}, a2 = {a, a};
+#if RT_VARIANT == 4
+    const float inv_len = (1.0f / sqrtf(a)) * (1.0f + 0x1p-19f);
+    const V3 uf = v3(d.x * inv_len, d.y * inv_len, d.z * inv_len);
 #endif
     for (uint32_t blk = 0; blk < count; blk += 32u) {
         const uint32_t k = (count - blk) < 32u ? (count - blk) : 32u;   // spheres in this block, multiple of 8
@@ -183,25 +183,22 @@ RT_DEV void scan_tile(const float4* __restrict__ tile, uint32_t count, int base,
         for (uint32_t i = 0; i < k; i += RT_SCAN_UNROLL) {
             float4 s[RT_SCAN_UNROLL];
 #pragma unroll
-            for (uint32_t u = 0; u < RT_SCAN_UNROLL; u++) s[u] = tile[blk + i + u];
+            for (uint32_t u = 0; u < RT_SCAN_UNROLL; u++) s[u] = tile.geo[blk + i + u];
 #pragma unroll
-            for (uint32_t u = 0; u < RT_SCAN_UNROLL; u += 2) {
-                const float4 A = s[u], B = s[u + 1];
-#if RT_VARIANT == 3
-                const f2 ocx = f2{A.x, A.y} - ox, ocy = f2{A.z, A.w} - oy, ocz = f2{B.x, B.y} - oz;
-                const f2 h = pk_fma(dz, ocz, pk_fma(dy, ocy, dx * ocx));
-                const f2 ncc = pk_fma(-ocz, ocz, pk_fma(-ocy, ocy, pk_fma(-ocx, ocx, f2{B.z, B.w})));
-                const f2 disc = pk_fma(h, h, a2 * ncc);
-                const float h0 = h.x, h1 = h.y, n0 = ncc.x, n1 = ncc.y, q0 = disc.x, q1 = disc.y;
+            for (uint32_t u = 0; u < RT_SCAN_UNROLL; u++) {
+#if RT_VARIANT == 4
+                const float ocx = s[u].x - o.x, ocy = s[u].y - o.y, ocz = s[u].z - o.z;
+                const float hf = fmaf(uf.z, ocz, fmaf(uf.y, ocy, uf.x * ocx));
+                const float nf = fmaf(-ocz, ocz, fmaf(-ocy, ocy, fmaf(-ocx, ocx, s[u].w)));
+                const uint32_t key = __float_as_uint(fmaf(hf, hf, nf));
 #else
-                float h0, n0, q0, h1, n1, q1;
-                sphere_terms(A.x, A.z, B.x, B.z, o, d, a, h0, n0, q0);
-                sphere_terms(A.y, A.w, B.y, B.w, o, d, a, h1, n1, q1);
+                // exact terms (on the inflated r*r, still a superset) and the sign trick
+                // key = (h & ncc) | disc: clear sign iff disc >= 0 and (h > 0 or ncc > 0); 13 operations
+                float h, n, q;
+                sphere_terms(s[u].x, s[u].y, s[u].z, s[u].w, o, d, a, h, n, q);
+                const uint32_t key = (__float_as_uint(h) & __float_as_uint(n)) | __float_as_uint(q);
 #endif
-                uint32_t key0 = (__float_as_uint(h0) & __float_as_uint(n0)) | __float_as_uint(q0);
-                uint32_t key1 = (__float_as_uint(h1) & __float_as_uint(n1)) | __float_as_uint(q1);
-                miss = __builtin_amdgcn_alignbit(miss, key0, 31u);
-                miss = __builtin_amdgcn_alignbit(miss, key1, 31u);
+                miss = __builtin_amdgcn_alignbit(miss, key, 31u);
             }
         }
         uint32_t bits = ~miss & (k == 32u ? 0xffffffffu : ((1u << k) - 1u));
@@ -221,7 +218,8 @@ RT_DEV void scan_tile(const float4* __restrict__ tile, uint32_t count, int base,
 
 // ---------------------------------------------------------------- shading
 struct Scene {
-    const float4* __restrict__ geom;    // scan data in the tile layout above, n_padded float4
+    const float4* __restrict__ geom;    // {cx, cy, cz, rr_f} per sphere, n_padded entries
+    const float* __restrict__ rrx;      // exact r*r per sphere, n_padded entries
     const float4* __restrict__ shade;   // per sphere two float4: {cx, cy, cz, radius}, {albedo r, g, b, fuzz | ior}
     const uint32_t* __restrict__ mat;   // material tag per sphere
 };
@@ -349,16 +347,24 @@ RT_DEV bool map_pixel(const RtLaunch& L, uint32_t wave_tile, uint32_t lane, uint
     return wave_tile < L.n_wave_tiles && x < L.width && ly < L.rows_local && y < L.height;
 }
 
-RT_DEV void stage_tile(float4* tile, const float4* __restrict__ geom, uint32_t first, uint32_t count) {
-    for (uint32_t i = threadIdx.x; i < count; i += blockDim.x) tile[i] = geom[first + i];
+// Dynamic LDS: [geo: T float4][rrx: T float][candidate lists: waves x RT_CAND_CAP x 64 u16],
+// T = min(n_padded, RT_TILE_SPHERES)
+extern __shared__ float4 rt_lds[];
+
+RT_DEV uint32_t tile_capacity(const RtLaunch& L) { return L.n_padded < RT_TILE_SPHERES ? L.n_padded : RT_TILE_SPHERES; }
+
+RT_DEV Tile stage_tile(const RtLaunch& L, const float4* __restrict__ geom, const float* __restrict__ rrx,
+                       uint32_t first, uint32_t count) {
+    float4* geo = rt_lds;
+    float* rr = reinterpret_cast<float*>(rt_lds + tile_capacity(L));
+    for (uint32_t i = threadIdx.x; i < count; i += blockDim.x) { geo[i] = geom[first + i]; rr[i] = rrx[first + i]; }
+    Tile t = {geo, rr};
+    return t;
 }
 
-// Dynamic LDS: [sphere tile: min(n_padded, RT_TILE_SPHERES) float4][candidate lists: waves x RT_CAND_CAP x 64 u16]
-extern __shared__ float4 rt_lds_tile[];
-
 RT_DEV Cand cand_list(const RtLaunch& L) {
-    uint32_t tile_spheres = L.n_padded < RT_TILE_SPHERES ? L.n_padded : RT_TILE_SPHERES;
-    uint16_t* base = reinterpret_cast<uint16_t*>(rt_lds_tile + tile_spheres);
+    uint32_t cap = tile_capacity(L);
+    uint16_t* base = reinterpret_cast<uint16_t*>(reinterpret_cast<float*>(rt_lds + cap) + cap);
     Cand c;
     c.col = base + (threadIdx.x >> 6) * (RT_CAND_CAP * 64u) + (threadIdx.x & 63u);
     c.n = 0u;
@@ -376,7 +382,6 @@ RT_DEV Cand cand_list(const RtLaunch& L) {
 template <bool MULTI>
 RT_DEV void render_body(const Scene& sc, uint32_t* __restrict__ rgba, float4* __restrict__ linear,
                         unsigned long long* __restrict__ segments, const RtCamera& cam, const RtLaunch& L) {
-    float4* tile = rt_lds_tile;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave_tile = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const uint64_t seed = ((uint64_t)L.seed_hi << 32) | L.seed_lo;
@@ -386,8 +391,9 @@ RT_DEV void render_body(const Scene& sc, uint32_t* __restrict__ rgba, float4* __
     const bool valid = map_pixel(L, wave_tile, lane, x, ly, y);
     const uint32_t pixel = y * L.width + x;
 
+    Tile tile = {rt_lds, reinterpret_cast<const float*>(rt_lds + tile_capacity(L))};
     if (!MULTI) {
-        stage_tile(tile, sc.geom, 0u, L.n_padded);
+        tile = stage_tile(L, sc.geom, sc.rrx, 0u, L.n_padded);
         __syncthreads();
     }
 
@@ -422,7 +428,7 @@ RT_DEV void render_body(const Scene& sc, uint32_t* __restrict__ rgba, float4* __
                 uint32_t count = L.n_padded - first;
                 if (count > RT_TILE_SPHERES) count = RT_TILE_SPHERES;
                 if (first) __syncthreads();                      // previous tile fully scanned
-                stage_tile(tile, sc.geom, first, count);
+                tile = stage_tile(L, sc.geom, sc.rrx, first, count);
                 __syncthreads();
                 if (active) scan_tile(tile, count, (int)first, o, d, a, L.t_min, b, cand, st);
             }
@@ -493,24 +499,23 @@ RT_DEV void render_body(const Scene& sc, uint32_t* __restrict__ rgba, float4* __
 }
 
 extern "C" __global__ void __launch_bounds__(1024)
-rt_render(const float4* geom, const float4* shade, const uint32_t* mat, uint32_t* rgba, float4* linear,
-          unsigned long long* segments, RtCamera cam, RtLaunch L) {
-    Scene sc = {geom, shade, mat};
+rt_render(const float4* geom, const float* rrx, const float4* shade, const uint32_t* mat, uint32_t* rgba,
+          float4* linear, unsigned long long* segments, RtCamera cam, RtLaunch L) {
+    Scene sc = {geom, rrx, shade, mat};
     render_body<false>(sc, rgba, linear, segments, cam, L);
 }
 
 extern "C" __global__ void __launch_bounds__(1024)
-rt_render_stream(const float4* geom, const float4* shade, const uint32_t* mat, uint32_t* rgba, float4* linear,
-                 unsigned long long* segments, RtCamera cam, RtLaunch L) {
-    Scene sc = {geom, shade, mat};
+rt_render_stream(const float4* geom, const float* rrx, const float4* shade, const uint32_t* mat, uint32_t* rgba,
+                 float4* linear, unsigned long long* segments, RtCamera cam, RtLaunch L) {
+    Scene sc = {geom, rrx, shade, mat};
     render_body<true>(sc, rgba, linear, segments, cam, L);
 }
 
 // ---------------------------------------------------------------- primary-hit index map
 // Closest sphere index (or -1) of the ray through each pixel centre (sub-pixel offset 0).
 extern "C" __global__ void __launch_bounds__(1024)
-rt_primary_hits(const float4* geom, int32_t* hits, RtCamera cam, RtLaunch L) {
-    float4* tile = rt_lds_tile;
+rt_primary_hits(const float4* geom, const float* rrx, int32_t* hits, RtCamera cam, RtLaunch L) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave_tile = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     uint32_t x, ly, y;
@@ -527,7 +532,7 @@ rt_primary_hits(const float4* geom, int32_t* hits, RtCamera cam, RtLaunch L) {
         uint32_t count = L.n_padded - first;
         if (count > RT_TILE_SPHERES) count = RT_TILE_SPHERES;
         if (first) __syncthreads();
-        stage_tile(tile, geom, first, count);
+        Tile tile = stage_tile(L, geom, rrx, first, count);
         __syncthreads();
         if (valid) scan_tile(tile, count, (int)first, o, d, a, L.t_min, b, cand, st);
     }
