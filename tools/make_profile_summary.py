@@ -1,0 +1,78 @@
+"""Condenses a gpurun_out/prof_rNN directory (rocprofv3 --kernel-trace --stats run + separate --pmc passes of
+bench.py) into the files kept under profiles/:  python tools/make_profile_summary.py gpurun_out/prof_r01 r01"""
+import collections, csv, glob, json, os, re, sys
+
+src, tag = sys.argv[1], sys.argv[2]
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+dst = os.path.join(root, "profiles")
+os.makedirs(dst, exist_ok=True)
+
+# 1. kernel-trace --stats summary (verbatim rows, long torch kernel names shortened)
+stats = glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)[0]
+with open(stats) as f, open(os.path.join(dst, f"{tag}_kernel_stats.csv"), "w") as g:
+    for row in csv.reader(f):
+        row[0] = row[0][:80]
+        g.write(",".join(f'"{c}"' for c in row) + "\n")
+trace = glob.glob(os.path.join(src, "trace", "**", "*kernel_trace.csv"), recursive=True)[0]
+durs = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in csv.DictReader(open(trace)) if r["Kernel_Name"] == "rt_render"]
+bench_line = [l for l in open(os.path.join(src, "trace.log")) if l.startswith("{")][-1]
+bench = json.loads(bench_line)
+
+# 2. PMC passes
+pmc = collections.defaultdict(float)
+meta = {}
+for f in glob.glob(os.path.join(src, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
+    per = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if r["Kernel_Name"] != "rt_render":
+            continue
+        per[(r["Counter_Name"], r["Dispatch_Id"])].append(float(r["Counter_Value"]))
+        meta = {"VGPR_Count": r["VGPR_Count"], "SGPR_Count": r["SGPR_Count"], "Workgroup_Size": r["Workgroup_Size"], "Grid_Size": r["Grid_Size"]}
+    byname = collections.defaultdict(list)
+    for (name, _), vals in per.items():
+        byname[name].append(sum(vals))
+    for name, vals in byname.items():
+        pmc[name] = sum(vals) / len(vals)
+
+seg = bench["roofline"]["segments_per_launch"]
+lines = []
+w = lines.append
+w(f"# {tag}: rocprofv3 summary of `python bench.py` (book-1 final scene, 3840x2160, 500 spp, depth 50, 1 x MI355X)")
+w(f"kernel-trace: rt_render {len(durs)} dispatches, durations ms {['%.1f' % d for d in durs]}, average {sum(durs) / len(durs):.1f} ms")
+w(f"bench.py in the same run: kernel_ms {bench['roofline']['kernel_ms']:.1f} (HIP events in the library), value {bench['value']:.1f} Mrays/s, "
+  f"roofline {bench['roofline']['achieved']:.2f} TFLOP/s = {100 * bench['roofline']['frac']:.1f} % of {bench['roofline']['peak']}")
+w(f"dispatch: {meta}")
+w("")
+w("PMC (separate passes, one dispatch each, summed over the chip):")
+for k in sorted(pmc):
+    w(f"  {k:28s} {pmc[k]:20.0f}")
+w("")
+w("derived:")
+if pmc.get("SQ_INSTS_VALU"):
+    w(f"  ray segments per launch            {seg:.0f}")
+    w(f"  VALU wave-instructions per segment {pmc['SQ_INSTS_VALU'] / seg * 64:.1f} per 64-lane wavefront pass (scan floor 488 x 11 = 5368)")
+    w(f"  active lanes per VALU instruction  {pmc['SQ_THREAD_CYCLES_VALU'] / pmc['SQ_INSTS_VALU']:.1f} of 64 ({100 * pmc['SQ_THREAD_CYCLES_VALU'] / pmc['SQ_INSTS_VALU'] / 64:.1f} %)")
+    w(f"  LDS instructions per VALU instr    {pmc['SQ_INSTS_LDS'] / pmc['SQ_INSTS_VALU']:.3f}")
+    w(f"  SALU instructions per VALU instr   {pmc['SQ_INSTS_SALU'] / pmc['SQ_INSTS_VALU']:.3f}")
+if pmc.get("SQ_LDS_IDX_ACTIVE"):
+    w(f"  LDS bank-conflict cycles / LDS active cycles  {pmc['SQ_LDS_BANK_CONFLICT'] / pmc['SQ_LDS_IDX_ACTIVE']:.5f}")
+if pmc.get("GRBM_GUI_ACTIVE"):
+    k_s = sum(durs) / len(durs) * 1e-3
+    clk = pmc["GRBM_GUI_ACTIVE"] / 8 / k_s
+    w(f"  effective shader clock             {clk / 1e9:.2f} GHz (GRBM_GUI_ACTIVE / 8 XCDs / kernel time)")
+    w(f"  VALU wave-instructions per SIMD per cycle  {pmc['SQ_INSTS_VALU'] / 1024 / (pmc['GRBM_GUI_ACTIVE'] / 8):.3f} (one wave64 VALU instruction occupies a SIMD-32 for 2 cycles: ceiling 0.5)")
+    w(f"  resident waves per SIMD (SQ_WAVE_CYCLES*4 / cycles / 1024)  {pmc['SQ_WAVE_CYCLES'] * 4 / (pmc['GRBM_GUI_ACTIVE'] / 8) / 1024:.2f}" if pmc.get("SQ_WAVE_CYCLES") else "")
+hbm = None
+if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
+    # FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half of a wide coalesced read stream
+    fetch = pmc["FETCH_SIZE"] * 1024 * 2
+    write = pmc["WRITE_SIZE"] * 1024
+    hbm = fetch + write
+    w(f"  HBM traffic per launch             {hbm / 1e6:.1f} MB (FETCH_SIZE {pmc['FETCH_SIZE']:.0f} KiB x2 gfx950 correction + WRITE_SIZE {pmc['WRITE_SIZE']:.0f} KiB);"
+      f" algorithmic bytes: 3840*2160*4 B frame = 33.2 MB + 31 KB scene")
+open(os.path.join(dst, f"{tag}_rocprof_summary.txt"), "w").write("\n".join(l for l in lines) + "\n")
+if hbm is not None:
+    json.dump({"hbm_bytes_per_launch": hbm, "fetch_size_kib": pmc["FETCH_SIZE"], "write_size_kib": pmc["WRITE_SIZE"],
+               "note": "rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in separate passes of bench.py --steps 1; FETCH_SIZE doubled (gfx950 correction)"},
+              open(os.path.join(dst, f"{tag}_hbm_traffic.json"), "w"))
+print("\n".join(lines))
