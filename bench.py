@@ -29,7 +29,6 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 FP32_VECTOR_PEAK_TFLOPS = 157.3   # MI355X vector FP32 peak: 256 CU x 2.4 GHz x 256 FLOP/clk/CU
-TILE_ROWS = 8
 
 
 def parse():
@@ -68,6 +67,8 @@ def main():
     import torch
     import torch.distributed as dist
     import ray_tracing_amd as rt
+    from ray_tracing_amd import tiles
+    TILE_ROWS = tiles.TILE_ROWS
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -89,24 +90,14 @@ def main():
     params = rt.DeviceGUI(samples_per_pixel=args.spp, max_depth=args.depth, seed=1, block_dim=args.block_dim)
     hip = rt.HipWorld(local_rank, spheres)
 
-    n_tiles = (H + TILE_ROWS - 1) // TILE_ROWS
-    my_tiles = len(range(rank, n_tiles, world))
-    max_tiles = (n_tiles + world - 1) // world
-    # compact per-rank buffer, padded to the largest per-rank tile count so the gather is uniform
-    d_rgba = torch.zeros((max_tiles * TILE_ROWS, W, 4), dtype=torch.uint8, device=dev)
+    my_tiles = len(tiles.tiles_of_rank(H, rank, world))
+    d_rgba = tiles.local_buffer(H, W, world, dev)          # compact per-rank buffer
     gathered = [torch.empty_like(d_rgba) for _ in range(world)] if (world > 1 and rank == 0) else None
 
     def step():
         rays, ms = hip.render_tiles_device(cam, params, TILE_ROWS, rank, world, my_tiles, d_rgba.data_ptr())
-        frame = None
-        if world > 1:
-            dist.gather(d_rgba, gathered, dst=0)          # RCCL over xGMI; 8-row tiles, <= 4.2 MB per peer at 4K
-            if rank == 0:
-                # tile t = k*world + r sits at gathered[r][k]: stack as [k][r] and flatten
-                g = torch.stack(gathered, 0).view(world, max_tiles, TILE_ROWS, W, 4)
-                frame = g.permute(1, 0, 2, 3, 4).reshape(max_tiles * world * TILE_ROWS, W, 4)[:H]
-        else:
-            frame = d_rgba[:H]
+        # RCCL gather over xGMI (<= 4.2 MB per peer at 4K) + de-interleave on rank 0
+        frame = tiles.gather_frame(d_rgba, H, rank, world, gathered)
         return rays, ms, frame
 
     def fence():

@@ -1,0 +1,127 @@
+"""The C-ABI library loads without a GPU and exports every symbol include/rt_hip.h declares; host-side helpers
+(camera set-up, scene builders, PPM writer) against the CPU checker and the reference's constants.
+No compute calls are made here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def rt():
+    import ray_tracing_amd
+    return ray_tracing_amd
+
+
+def declared_functions():
+    text = open(os.path.join(ROOT, "include", "rt_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rt_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported(rt):
+    names = declared_functions()
+    assert len(names) >= 20
+    lib = C.CDLL(rt._ffi.LIB_PATH)
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/rt_hip.h but not exported"
+    # and the binding table covers exactly the header
+    assert sorted(rt._ffi.SYMBOLS) == names
+
+
+def test_struct_layouts_match_reference_abi(rt):
+    """Offsets of the 148-byte camera block (ray_tracing.rs:251-272 / library.cu:54-75) and the 36-byte sphere."""
+    cam = rt.RtCamera
+    want = {"aspect_ratio": 0, "image_width": 4, "samples_per_pixel": 8, "max_depth": 12, "vfov": 16, "lookfrom": 20,
+            "lookat": 32, "vup": 44, "image_height": 56, "pixel_samples_scale": 60, "center": 64, "pixel00_loc": 76,
+            "pixel_delta_u": 88, "pixel_delta_v": 100, "u": 112, "v": 124, "w": 136}
+    for name, off in want.items():
+        assert getattr(cam, name).offset == off, name
+    assert C.sizeof(cam) == 148
+    assert rt.SPHERE_DTYPE.itemsize == 36
+    assert C.sizeof(rt.RtParams) == 40
+
+
+def test_create_without_gpu_returns_an_error_not_a_crash(rt):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(rt.RtError) as e:
+        rt.HipWorld(0)
+    assert "hip" in str(e.value).lower()
+
+
+def test_look_at_camera_equals_checker(rt, oracle):
+    """rt_camera_initialize vs the checker's restatement of ray_tracing.rs:300-336: same bytes."""
+    for (w, vfov, frm, at) in [(1280, 90.0, (-2, 2, 1), (0, 0, -1)), (3840, 20.0, (13, 2, 3), (0, 0, 0)),
+                               (257, 35.5, (0.5, -3, 9), (1, 1, 1)), (64, 90.0, (0, 0, -85), (0, 0, -70))]:
+        cam = rt.Camera.look_at(16.0 / 9.0, w, vfov, frm, at)
+        ref = oracle.RtCamera()
+        C.memmove(C.addressof(ref), C.addressof(cam.block), 148)
+        for f in ("pixel00_loc", "pixel_delta_u", "pixel_delta_v", "u", "v", "w", "center"):
+            getattr(ref, f)[:] = [0.0, 0.0, 0.0]
+        ref.image_height = 0
+        oracle.lib().or32_camera_initialize(C.addressof(ref))
+        assert bytes(ref) == bytes(cam.block)
+    d = rt.Camera.new(16.0 / 9.0, 1280)           # reference defaults, ray_tracing.rs:276-294
+    assert d.image_height == 720 and d.block.vfov == 90.0 and list(d.block.lookfrom) == [-2.0, 2.0, 1.0]
+    assert d.block.samples_per_pixel == 10 and d.block.max_depth == 10
+
+
+def test_cpu_camera_equals_checker(rt, oracle):
+    """rt_camera_new_cpu vs the checker's f64 Camera::new (lib.rs:148-183) rounded to f32."""
+    for w in (256, 1920, 5, 1000):
+        cam = rt.Camera.new_cpu(16.0 / 9.0, w)
+        ref = oracle.camera_f32_from_d(oracle.camera_new_f64(16.0 / 9.0, w))
+        got = oracle.camera_f32_from_rt(cam.block)
+        assert bytes(ref) == bytes(got)
+    assert rt.Camera.new_cpu(16.0 / 9.0, 256).image_height == 144
+    with pytest.raises(rt.RtError):
+        rt.Camera.new_cpu(16.0 / 9.0, 0)
+
+
+def test_scene_builders(rt):
+    cpu = rt.scene_cpu_default()                    # main.rs:26-28
+    assert len(cpu) == 2 and list(cpu[0]["center"]) == [0.0, 0.0, -1.0] and cpu[1]["radius"] == 100.0
+    gpu = rt.scene_gpu_default()                    # ray.cu:97-106
+    assert len(gpu) == 9
+    assert list(gpu["material"]) == [1, 1, 2, 2, 2, 2, 2, 1, 2]
+    assert gpu[3]["param"] == 1.0 and np.isclose(gpu[2]["param"], 0.3) and gpu[5]["radius"] == 25.0
+    b = rt.scene_book1_final(1)
+    assert 470 <= len(b) <= 488 and b[0]["radius"] == 1000.0
+    assert np.array_equal(b, rt.scene_book1_final(1)) and not np.array_equal(b, rt.scene_book1_final(2))
+    small = b[1:-3]
+    assert (small["radius"] == np.float32(0.2)).all() and set(np.unique(small["material"])) == {1, 2, 3}
+    assert (np.hypot(small["center"][:, 0] - 4.0, small["center"][:, 2]) > 0.9).all()
+    assert (b[b["material"] == 2]["param"] <= 1.0).all() and (b[b["material"] == 3]["param"] == 1.5).all()
+    g = rt.scene_grid(2, 128)
+    assert len(g) == 16385 and (g[1:]["radius"] < 0.45).all()
+    assert len(rt.scene_grid(2, 4)) == 17
+    h = rt.scene_mirror_hall(3, 64)
+    assert len(h) == 66 and h[0]["radius"] == 25.0 and h[1]["center"][2] == -110.0
+    # Reflect(color, fuzz) clamps fuzz to 1 (library.cu:144)
+    assert rt.Reflect((1, 1, 1), 7.0)[2] == 1.0
+    s = rt.Sphere((1, 2, 3), 0.5, rt.Dielectric(1.5))
+    assert s["material"] == 3 and s["param"] == 1.5
+    w = rt.world([rt.Sphere((0, 0, -1), 0.5), s])
+    assert w.dtype == rt.SPHERE_DTYPE and len(w) == 2 and w[0]["material"] == 1
+
+
+def test_ppm_writer(rt, tmp_path):
+    img = np.zeros((3, 5, 4), np.uint8)
+    img[..., 0] = np.arange(5)[None, :] * 50
+    img[..., 1] = np.arange(3)[:, None] * 100
+    img[..., 2] = 7
+    img[..., 3] = 255
+    path = tmp_path / "x.ppm"
+    rt.write_ppm(path, img)
+    data = open(path, "rb").read()
+    assert data.startswith(b"P6\n5 3\n255\n")
+    body = np.frombuffer(data[len(b"P6\n5 3\n255\n"):], np.uint8).reshape(3, 5, 3)
+    assert np.array_equal(body, img[..., :3])
+    with pytest.raises(rt.RtError):
+        rt.write_ppm("/nonexistent-dir/x.ppm", img)

@@ -1,0 +1,79 @@
+"""The N > 1 path on CPU: two gloo ranks render their interleaved row tiles (with the CPU checker standing in
+for the GPU kernel), gather to rank 0 with the same code bench.py uses (ray_tracing_amd/tiles.py), and the
+assembled frame must equal the single-rank frame bit for bit."""
+import os
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = textwrap.dedent("""
+    import os, sys
+    sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "tests"))
+    import numpy as np, torch, torch.distributed as dist
+    import oracle_ffi as o
+    import ray_tracing_amd as rt
+    from ray_tracing_amd import tiles
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo")
+    sp = rt.scene_gpu_default()
+    cam = rt.Camera.new(16.0 / 9.0, 72)             # 72 x 40: five 8-row tiles, uneven over 2 and 3 ranks
+    p = rt.DeviceGUI(samples_per_pixel=3, max_depth=6, seed=5)
+    ocam = o.camera_f32_from_rt(cam.block)
+    H, W = cam.image_height, cam.image_width
+    local = tiles.local_buffer(H, W, world, "cpu")
+    rays = 0
+    for k, t in enumerate(tiles.tiles_of_rank(H, rank, world)):
+        r0 = t * tiles.TILE_ROWS
+        rows = min(tiles.TILE_ROWS, H - r0)
+        rgba, _, seg = o.render(ocam, sp, p, row0=r0, rows=rows, threads=2)
+        local[k * tiles.TILE_ROWS:k * tiles.TILE_ROWS + rows] = torch.from_numpy(rgba)
+        rays += seg
+    frame = tiles.gather_frame(local, H, rank, world)
+    total = torch.tensor([rays], dtype=torch.int64)
+    dist.all_reduce(total)
+    if rank == 0:
+        np.save(os.environ["OUT_NPY"], frame.numpy())
+        open(os.environ["OUT_NPY"] + ".rays", "w").write(str(int(total.item())))
+    else:
+        assert frame is None
+    dist.barrier()
+    dist.destroy_process_group()
+""")
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_gloo_ranks_assemble_the_single_rank_frame(tmp_path, oracle, world):
+    import ray_tracing_amd as rt
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % {"root": ROOT})
+    out = tmp_path / f"frame{world}.npy"
+    env = dict(os.environ, OUT_NPY=str(out), OMP_NUM_THREADS="1")
+    port = 29500 + (os.getpid() + world) % 400
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
+    assert res.returncode == 0, res.stderr[-2000:]
+    frame = np.load(out)
+    sp = rt.scene_gpu_default()
+    cam = rt.Camera.new(16.0 / 9.0, 72)
+    p = rt.DeviceGUI(samples_per_pixel=3, max_depth=6, seed=5)
+    rgba, _, seg = oracle.render(oracle.camera_f32_from_rt(cam.block), sp, p)
+    assert frame.shape == rgba.shape
+    assert np.array_equal(frame, rgba)
+    assert int(open(str(out) + ".rays").read()) == seg
+
+
+def test_tile_partition_covers_every_row_once():
+    from ray_tracing_amd import tiles
+    for H in (1, 8, 9, 76, 2160):
+        for world in (1, 2, 3, 8):
+            seen = []
+            for r in range(world):
+                seen += tiles.tiles_of_rank(H, r, world)
+                assert len(tiles.tiles_of_rank(H, r, world)) <= tiles.max_tiles_per_rank(H, world)
+            assert sorted(seen) == list(range(tiles.n_tiles(H)))

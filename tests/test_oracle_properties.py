@@ -1,0 +1,158 @@
+"""Properties of the CPU checker itself, at sizes that finish in seconds: the two precisions agree
+statistically, rendering is independent of thread count and row partition, and the reference's per-path
+rules (depth limit, band reflectance, quantisers, grid sampler) behave as the cited lines say."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+
+def params(o, **kw):
+    p = o.RtParams()
+    p.samples_per_pixel = kw.get("spp", 4)
+    p.sample2_per_pixel = kw.get("n2", 1)
+    p.max_depth = kw.get("depth", 10)
+    p.flags = kw.get("flags", 0)
+    p.seed = kw.get("seed", 0)
+    p.t_min = kw.get("t_min", 0.001)
+    p.t_max = kw.get("t_max", float("inf"))
+    return p
+
+
+def cpu_scene(o):
+    sp = np.zeros(2, o.SPHERE_DTYPE)
+    sp[0] = ((0.0, 0.0, -1.0), 0.5, 1, (0.5, 0.5, 0.5), 0.0)
+    sp[1] = ((0.0, -100.5, -1.0), 100.0, 1, (0.5, 0.5, 0.5), 0.0)
+    return sp
+
+
+def psnr(a, b):
+    mse = np.mean((a.astype(np.float64) - b.astype(np.float64)) ** 2)
+    return float("inf") if mse == 0 else 10.0 * np.log10(255.0 ** 2 / mse)
+
+
+LIBRS = 4 | 8 | 2  # band reflectance | sign-bit flip | rounding quantiser
+
+
+def test_f32_and_f64_agree_statistically(oracle):
+    camd = oracle.camera_new_f64(16.0 / 9.0, 128)
+    p = params(oracle, spp=32, depth=20, flags=LIBRS)
+    r64, l64, s64 = oracle.render(camd, cpu_scene(oracle), p)
+    r32, l32, s32 = oracle.render(oracle.camera_f32_from_d(camd), cpu_scene(oracle), p)
+    assert psnr(r32, r64) > 38.0
+    assert abs(s32 - s64) / s64 < 0.01
+    # most pixels follow identical paths in both precisions
+    assert np.median(np.abs(l32[..., :3] - l64[..., :3])) < 1e-5
+
+
+def test_threads_and_row_partition_do_not_change_the_image(oracle):
+    cam = oracle.camera_f32_from_d(oracle.camera_new_f64(16.0 / 9.0, 96))
+    p = params(oracle, spp=5, depth=8, flags=LIBRS, seed=3)
+    full = oracle.render(cam, cpu_scene(oracle), p, threads=1)
+    multi = oracle.render(cam, cpu_scene(oracle), p, threads=7)
+    assert np.array_equal(full[1], multi[1]) and full[2] == multi[2]
+    parts = [oracle.render(cam, cpu_scene(oracle), p, row0=r0, rows=n) for r0, n in ((0, 10), (10, 1), (11, 43))]
+    assert np.array_equal(np.concatenate([x[1] for x in parts]), full[1])
+    assert sum(x[2] for x in parts) == full[2]
+
+
+def test_depth_limit_counts_segments(oracle):
+    """A path has at most max_depth segments; the max_depth-th call returns black (lib.rs:190-192, ray.cu:29-32)."""
+    cam = oracle.camera_f32_from_d(oracle.camera_new_f64(16.0 / 9.0, 64))
+    n_px = 64 * 36
+    rgba, lin, seg = oracle.render(cam, cpu_scene(oracle), params(oracle, spp=3, depth=0))
+    assert seg == 0 and not lin[..., :3].any() and (rgba[..., 3] == 255).all()
+    rgba, lin, seg = oracle.render(cam, cpu_scene(oracle), params(oracle, spp=3, depth=1))
+    assert seg == 3 * n_px
+    hit = oracle.primary_hits(cam, cpu_scene(oracle)) >= 0
+    inner = hit.copy()                              # pixels whose 3x3 neighbourhood hits: every jittered sample hits too
+    for dy in (-1, 0, 1):
+        for dx in (-1, 0, 1):
+            inner &= np.roll(np.roll(hit, dy, 0), dx, 1)
+    inner[0] = inner[-1] = False
+    inner[:, 0] = inner[:, -1] = False
+    assert inner.sum() > 100 and not lin[inner][:, :3].any()   # cut off after the first segment: black
+    rgba, lin, seg = oracle.render(cam, cpu_scene(oracle), params(oracle, spp=3, depth=50))
+    assert 3 * n_px < seg <= 50 * 3 * n_px
+
+
+def test_band_reflectance_columns(oracle):
+    """lib.rs:225-226: reflectance 0.1 + 0.2*(x / (W/5)); with W = 256 the last column falls in a sixth band."""
+    cam = oracle.camera_f32_from_d(oracle.camera_new_f64(16.0 / 9.0, 256))
+    sky_only = np.zeros(0, oracle.SPHERE_DTYPE)
+    # grid sampler with n = 1: the single sample goes through the pixel centre
+    _, lin, _ = oracle.render(cam, sky_only, params(oracle, spp=1, n2=1, depth=5, flags=LIBRS | 1), row0=0, rows=1)
+    o3, d3 = (C.c_float * 3)(), (C.c_float * 3)()
+    band = []
+    for x in range(256):
+        oracle.lib().or32_pixel_center_ray(C.byref(cam), x, 0, o3, d3)
+        d = np.array(d3[:], np.float64)
+        uy = d[1] / np.linalg.norm(d)
+        a = (1.0 - float(lin[0, x, 0])) / 0.5        # red = (1-a) + 0.5 a  (lib.rs:204-205)
+        band.append(a / (uy + 1.0))
+    band = np.round(np.array(band), 3)
+    want = np.round(0.1 + 0.2 * (np.arange(256) // 51), 3)
+    assert np.array_equal(band, want)
+    assert want[0] == 0.1 and want[51] == 0.3 and want[254] == 0.9 and want[255] == 1.1
+
+
+def test_quantisers(oracle):
+    """Rounding (lib.rs:236) vs truncation (ray.cu:81-89) of sqrt(x)*255."""
+    cam = oracle.camera_f32_from_d(oracle.camera_new_f64(16.0 / 9.0, 64))
+    sky_only = np.zeros(0, oracle.SPHERE_DTYPE)
+    r_round, lin, _ = oracle.render(cam, sky_only, params(oracle, spp=1, depth=5, flags=2))
+    r_trunc, lin2, _ = oracle.render(cam, sky_only, params(oracle, spp=1, depth=5, flags=0))
+    assert np.array_equal(lin, lin2)
+    v = np.sqrt(lin[..., :3].astype(np.float32)) * np.float32(255.0)
+    assert np.array_equal(r_trunc[..., :3], np.clip(v, 0, 255).astype(np.uint8))
+    assert np.array_equal(r_round[..., :3], np.clip(np.floor(v + np.float32(0.5)), 0, 255).astype(np.uint8))
+    assert (r_round[..., :3].astype(int) - r_trunc[..., :3].astype(int)).max() == 1
+
+
+def test_grid_sampler_is_deterministic_and_seed_free_on_sky(oracle):
+    """ray.cu:52-78: sample positions depend only on the sample index, so a scene without hits is seed-independent."""
+    cam = oracle.camera_f32_from_d(oracle.camera_new_f64(16.0 / 9.0, 48))
+    sky_only = np.zeros(0, oracle.SPHERE_DTYPE)
+    a = oracle.render(cam, sky_only, params(oracle, spp=9, n2=3, flags=1, seed=1))
+    b = oracle.render(cam, sky_only, params(oracle, spp=9, n2=3, flags=1, seed=2))
+    assert np.array_equal(a[1], b[1])
+    c = oracle.render(cam, sky_only, params(oracle, spp=9, flags=0, seed=1))
+    d = oracle.render(cam, sky_only, params(oracle, spp=9, flags=0, seed=2))
+    assert not np.array_equal(c[1], d[1])
+
+
+def test_closest_hit_keeps_lower_index_on_ties(oracle):
+    """Two identical spheres: the fold replaces only when strictly closer (lib.rs:127-135, ray.cu:5-15)."""
+    cam = oracle.camera_f32_from_d(oracle.camera_new_f64(16.0 / 9.0, 64))
+    sp = np.zeros(3, oracle.SPHERE_DTYPE)
+    sp[0] = ((0.0, 0.0, -3.0), 0.5, 1, (0.5, 0.5, 0.5), 0.0)
+    sp[1] = ((0.0, 0.0, -1.0), 0.5, 1, (0.5, 0.5, 0.5), 0.0)
+    sp[2] = ((0.0, 0.0, -1.0), 0.5, 1, (0.5, 0.5, 0.5), 0.0)
+    hits = oracle.primary_hits(cam, sp)
+    assert set(np.unique(hits)) == {-1, 1}
+    # origin inside a sphere: the far root is taken (lib.rs:110-116)
+    big = np.zeros(1, oracle.SPHERE_DTYPE)
+    big[0] = ((0.0, 0.0, 0.0), 5.0, 1, (0.5, 0.5, 0.5), 0.0)
+    idx, t, point, normal = oracle.primary_hits(cam, big, details=True)
+    assert (idx == 0).all() and (t > 0).all()
+    assert np.allclose(np.linalg.norm(point, axis=-1), 5.0, rtol=1e-5)
+    assert (np.einsum("ijk,ijk->ij", normal, point) < 0).all()   # normal flipped to face the ray
+
+
+def test_rng_streams_are_distinct(oracle):
+    L = oracle.lib()
+    seen = set()
+    for pixel in range(4):
+        for sample in range(4):
+            for k in range(4):
+                st, inc = C.c_uint64(0), C.c_uint64(0)
+                L.or_stream_init(C.byref(st), C.byref(inc), 42, pixel, sample, k)
+                first = tuple(L.or_pcg32_next(C.byref(st), inc.value) for _ in range(2))
+                assert inc.value == 2 * pixel + 1
+                seen.add(first)
+    assert len(seen) == 64
+    # statistical sanity of the [0,1) mapping
+    st, inc = C.c_uint64(0), C.c_uint64(0)
+    L.or_stream_init(C.byref(st), C.byref(inc), 1, 2, 3, 4)
+    u = np.array([L.or_u01(L.or_pcg32_next(C.byref(st), inc.value)) for _ in range(20000)])
+    assert 0.49 < u.mean() < 0.51 and 0.08 < u.var() < 0.087 and u.min() >= 0.0 and u.max() < 1.0
