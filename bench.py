@@ -93,6 +93,7 @@ def main():
     my_tiles = len(tiles.tiles_of_rank(H, rank, world))
     d_rgba = tiles.local_buffer(H, W, world, dev)          # compact per-rank buffer
     gathered = [torch.empty_like(d_rgba) for _ in range(world)] if (world > 1 and rank == 0) else None
+    torch.cuda.synchronize()                               # buffers zero-filled before the library's stream writes them
 
     def step():
         rays, ms = hip.render_tiles_device(cam, params, TILE_ROWS, rank, world, my_tiles, d_rgba.data_ptr())

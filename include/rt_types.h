@@ -88,7 +88,14 @@ typedef struct RtParams {
     float    t_min;              /* 0.001 in both reference paths (lib.rs:193, ray.cu:24) */
     float    t_max;              /* +inf on the CPU path (lib.rs:193), 10024 on the GPU path (ray.cu:24) */
     uint32_t block_dim;          /* threads per workgroup, multiple of 64 in 64..1024 (ray_tracing.rs:59,190-192); 0 = library default */
-    uint32_t reserved;
+    /* Accumulation of the samples of a pixel.
+     * 0: all samples are added in order in fp32, the reference's fold (lib.rs:228-231, ray.cu:123-129).
+     * C > 0 (and C < samples_per_pixel): runs of C consecutive samples are added in order in fp32; the run sums are
+     *    then added exactly (each converted to 2^-32 fixed point, 64-bit integer addition) and the mean is rounded
+     *    once.  Exact addition is order-independent, so the runs of a pixel can be traced by any lane at any time:
+     *    this is what lets the kernel hand samples to lanes dynamically.  Differs from the fold by rounding only
+     *    (about 1e-7 relative). */
+    uint32_t sample_chunk;
 } RtParams;
 
 #ifdef __cplusplus

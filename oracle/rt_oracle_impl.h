@@ -251,6 +251,24 @@ static inline V3 NAME(ray_color)(const NAME(Sph) *w, uint32_t n, V3 o, V3 d, con
     }
 }
 
+/* Run sum -> 2^-32 fixed point: floor part and the truncated fraction; values that are not finite and below
+ * 2^30 in magnitude count as 0 (RtParams.sample_chunk). */
+static inline int64_t NAME(to_fixed)(REAL x) {
+    if (!(R_FABS(x) < R(1073741824.0))) return 0;
+#if OR_F32
+    REAL hi = floorf(x);
+#else
+    REAL hi = floor(x);
+#endif
+    REAL frac = x - hi; /* exact, in [0,1) */
+    uint32_t lo = (uint32_t)(frac * R(4294967296.0)); /* truncation */
+    return (int64_t)((uint64_t)(int64_t)(int32_t)hi << 32) + (int64_t)lo;
+}
+
+static inline REAL NAME(fixed_mean)(int64_t sum, uint32_t spp) {
+    return (REAL)((double)sum * 0x1p-32 / (double)spp);
+}
+
 static inline uint8_t NAME(quant)(REAL lin, uint32_t flags) {
     REAL g = R_SQRT(lin); /* gamma 2 (lib.rs:236, ray.cu:129) */
     REAL v = g * R(255);
@@ -318,6 +336,8 @@ static void NAME(render_row)(NAME(Job) *jb, uint32_t lr) {
             band = R(0.1) + R(0.2) * R(x / (gi ? gi : 1));
         }
         V3 total = NAME(v3)(R(0), R(0), R(0));
+        const uint32_t chunk = (prm->sample_chunk && prm->sample_chunk < spp) ? prm->sample_chunk : 0;
+        int64_t fx = 0, fy = 0, fz = 0;
         for (uint32_t s = 0; s < spp; s++) {
             REAL si, sj;
             if (prm->flags & RT_FLAG_SAMPLER_GRID) { /* ray.cu:59-60 */
@@ -334,8 +354,13 @@ static void NAME(render_row)(NAME(Job) *jb, uint32_t lr) {
             NAME(make_ray)(cam, x, y, si, sj, &o, &d);
             V3 c = NAME(ray_color)(jb->w, jb->n, o, d, prm, pixel, s, band, &nseg);
             total = NAME(add)(total, c); /* lib.rs:228-231, ray.cu:126 */
+            if (chunk && ((s + 1) % chunk == 0 || s + 1 == spp)) { /* end of a run: exact accumulation */
+                fx += NAME(to_fixed)(total.x); fy += NAME(to_fixed)(total.y); fz += NAME(to_fixed)(total.z);
+                total = NAME(v3)(R(0), R(0), R(0));
+            }
         }
         V3 mean = NAME(v3)(total.x / R(spp), total.y / R(spp), total.z / R(spp));
+        if (chunk) mean = NAME(v3)(NAME(fixed_mean)(fx, spp), NAME(fixed_mean)(fy, spp), NAME(fixed_mean)(fz, spp));
         size_t k = (size_t)lr * W + x;
         if (jb->rgba) {
             jb->rgba[4 * k + 0] = NAME(quant)(mean.x, prm->flags);

@@ -134,10 +134,10 @@ class Camera:
 
 
 def DeviceGUI(sample2_per_pixel=4, block_dim=0, max_depth=4, samples_per_pixel=None, flags=None, seed=0,
-              t_min=0.001, t_max=10024.0):
+              t_min=0.001, t_max=10024.0, sample_chunk=0):
     """Per-frame knobs; the defaults are the reference's DeviceGUI::default (ray_tracing.rs:53-63) and the
     GPU path's t range (ray.cu:24).  With samples_per_pixel given the jitter sampler is used instead of the
-    n x n grid."""
+    n x n grid.  sample_chunk: see RtParams in include/rt_types.h (0 = the reference's fp32 fold)."""
     p = RtParams()
     if samples_per_pixel is None:
         p.samples_per_pixel = sample2_per_pixel * sample2_per_pixel
@@ -152,15 +152,16 @@ def DeviceGUI(sample2_per_pixel=4, block_dim=0, max_depth=4, samples_per_pixel=N
     p.t_min = t_min
     p.t_max = t_max
     p.block_dim = block_dim
+    p.sample_chunk = sample_chunk
     return p
 
 
-def cpu_params(samples_per_pixel=64, max_depth=20, seed=0, block_dim=0):
+def cpu_params(samples_per_pixel=64, max_depth=20, seed=0, block_dim=0, sample_chunk=0):
     """The CPU crate's behaviour (lib.rs:184-242 with main.rs:16-19 defaults): jittered samples, per-column
     reflectance bands, sign-bit flip rule, rounding quantiser, t in (0.001, inf)."""
     return DeviceGUI(samples_per_pixel=samples_per_pixel, max_depth=max_depth, seed=seed, block_dim=block_dim,
                      flags=RT_FLAG_BAND_ALBEDO | RT_FLAG_FLIP_SIGNBIT | RT_FLAG_QUANT_ROUND,
-                     t_min=0.001, t_max=float("inf"))
+                     t_min=0.001, t_max=float("inf"), sample_chunk=sample_chunk)
 
 
 # ---------------------------------------------------------------- device world

@@ -22,8 +22,14 @@ typedef struct RtLaunch {
     uint32_t rows_local;       // rows this launch renders (compact output buffer height)
     uint32_t tile_rows;        // local rows per row tile
     uint32_t tile_stride_rows; // global row distance between consecutive row tiles of this launch
-    uint32_t tiles_x;          // 8x8 wave tiles per image row = ceil(width / 8)
+    uint32_t tiles_x;          // 8x8 wave tiles per image row = ceil(width / 8)          (hit-map kernel)
     uint32_t n_wave_tiles;     // tiles_x * ceil(rows_local / 8)
+    // render kernels: one wavefront per unit of unit_w x unit_h pixels, samples cut into runs of `chunk`
+    uint32_t unit_w, unit_h;   // 8x8, 4x4 or 2x2; unit_h divides tile_rows
+    uint32_t units_x;          // ceil(width / unit_w)
+    uint32_t n_units;          // units_x * ceil(rows_local / unit_h)
+    uint32_t chunk;            // samples per work item (= samples_per_pixel when n_chunks == 1)
+    uint32_t n_chunks;         // ceil(samples_per_pixel / chunk); 1 = the reference's fp32 fold
 } RtLaunch;
 
 #define RT_SCAN_UNROLL 8u

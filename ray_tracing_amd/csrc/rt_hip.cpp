@@ -6,6 +6,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -135,26 +136,46 @@ RtLaunch make_launch(const rt_ctx* c, const RtCamera* cam, const RtParams* p, ui
     L.tile_stride_rows = tile_stride_rows;
     L.tiles_x = (cam->image_width + 7u) / 8u;
     L.n_wave_tiles = L.tiles_x * ((rows_local + 7u) / 8u);
+    // work decomposition of the render kernels
+    const uint32_t spp = p->samples_per_pixel ? p->samples_per_pixel : 1u;
+    if (p->sample_chunk == 0 || p->sample_chunk >= spp) {
+        L.chunk = spp; L.n_chunks = 1; L.unit_w = L.unit_h = 8;         // one lane per pixel, fp32 fold
+    } else {
+        L.chunk = p->sample_chunk;
+        L.n_chunks = (spp + L.chunk - 1u) / L.chunk;
+        // Unit size only affects scheduling (the sums are exact).  Smaller units even out the load between
+        // wavefronts when a launch has few pixels per SIMD; larger ones give each lane more items to even out
+        // the load inside the wavefront.
+        uint64_t pixels = (uint64_t)rows_local * cam->image_width;
+        uint32_t u = pixels >= (1ull << 22) ? 4u : 2u;
+        if ((uint64_t)u * u * L.n_chunks < 64u * 8u) u = 8u;             // too few items per lane: larger unit
+        const char* env = std::getenv("RT_UNIT");
+        if (env) { int v = std::atoi(env); if (v == 2 || v == 4 || v == 8) u = (uint32_t)v; }
+        L.unit_w = L.unit_h = u;
+    }
+    L.units_x = (cam->image_width + L.unit_w - 1u) / L.unit_w;
+    L.n_units = L.units_x * ((rows_local + L.unit_h - 1u) / L.unit_h);
     return L;
 }
 
-void launch_geometry(const RtParams* p, const RtLaunch& L, unsigned* grid, unsigned* block) {
+void launch_geometry(const RtParams* p, uint32_t n_wave_units, unsigned* grid, unsigned* block) {
     *block = p->block_dim ? p->block_dim : 256u;
     unsigned waves = *block / 64u;
-    *grid = (L.n_wave_tiles + waves - 1u) / waves;
+    *grid = (n_wave_units + waves - 1u) / waves;
 }
 
-// Dynamic LDS per workgroup: the sphere tile (float4 + exact r*r per sphere) plus one candidate-list block per wavefront.
+// Dynamic LDS per workgroup: the sphere tile (float4 + exact r*r per sphere) plus, per wavefront, one
+// candidate-list block and one block of pixel accumulators.
 size_t lds_bytes(const rt_ctx* c, unsigned block) {
     uint32_t n = c->n_padded < RT_TILE_SPHERES ? c->n_padded : RT_TILE_SPHERES;
-    return (size_t)n * 20u + (size_t)(block / 64u) * RT_CAND_CAP * 64u * 2u;
+    return (size_t)n * 20u + (size_t)(block / 64u) * (RT_CAND_CAP * 64u * 2u + 3u * 64u * 8u);
 }
 
 // One render launch into device buffers; blocking; fills last_ms and (optionally) the segment count.
 int launch_render(rt_ctx* c, const RtCamera* cam, const RtParams* p, RtLaunch L, void* d_rgba, void* d_linear,
                   uint64_t* rays_out) {
     unsigned grid, block;
-    launch_geometry(p, L, &grid, &block);
+    launch_geometry(p, L.n_units, &grid, &block);
     void* d_count = rays_out ? c->d_counter : nullptr;
     if (rays_out) RT_HIP(c, hipMemsetAsync(c->d_counter, 0, 64, c->stream));
     RtCamera cam_copy = *cam;
@@ -172,7 +193,7 @@ int launch_render(rt_ctx* c, const RtCamera* cam, const RtParams* p, RtLaunch L,
 
 int launch_hits(rt_ctx* c, const RtCamera* cam, const RtParams* p, RtLaunch L, void* d_hits) {
     unsigned grid, block;
-    launch_geometry(p, L, &grid, &block);
+    launch_geometry(p, L.n_wave_tiles, &grid, &block);
     RtCamera cam_copy = *cam;
     void* args[] = {&c->d_geom, &c->d_rrx, &d_hits, &cam_copy, &L};
     if (grid > 0)

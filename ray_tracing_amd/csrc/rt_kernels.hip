@@ -347,8 +347,8 @@ RT_DEV bool map_pixel(const RtLaunch& L, uint32_t wave_tile, uint32_t lane, uint
     return wave_tile < L.n_wave_tiles && x < L.width && ly < L.rows_local && y < L.height;
 }
 
-// Dynamic LDS: [geo: T float4][rrx: T float][candidate lists: waves x RT_CAND_CAP x 64 u16],
-// T = min(n_padded, RT_TILE_SPHERES)
+// Dynamic LDS: [geo: T float4][rrx: T float][candidate lists: waves x RT_CAND_CAP x 64 u16]
+// [accumulators: waves x 3 x 64 u64], T = min(n_padded, RT_TILE_SPHERES)
 extern __shared__ float4 rt_lds[];
 
 RT_DEV uint32_t tile_capacity(const RtLaunch& L) { return L.n_padded < RT_TILE_SPHERES ? L.n_padded : RT_TILE_SPHERES; }
@@ -362,6 +362,12 @@ RT_DEV Tile stage_tile(const RtLaunch& L, const float4* __restrict__ geom, const
     return t;
 }
 
+RT_DEV unsigned long long* accum_base(const RtLaunch& L) {
+    uint32_t cap = tile_capacity(L);
+    uint16_t* cand = reinterpret_cast<uint16_t*>(reinterpret_cast<float*>(rt_lds + cap) + cap);
+    return reinterpret_cast<unsigned long long*>(cand + (blockDim.x >> 6) * (RT_CAND_CAP * 64u));
+}
+
 RT_DEV Cand cand_list(const RtLaunch& L) {
     uint32_t cap = tile_capacity(L);
     uint16_t* base = reinterpret_cast<uint16_t*>(reinterpret_cast<float*>(rt_lds + cap) + cap);
@@ -372,26 +378,63 @@ RT_DEV Cand cand_list(const RtLaunch& L) {
 }
 
 // ---------------------------------------------------------------- render
+// Run sum -> 2^-32 fixed point (floor part + truncated fraction); values that are not finite and below
+// 2^30 in magnitude count as 0.  See RtParams.sample_chunk.
+RT_DEV long long to_fixed(float x) {
+    if (!(fabsf(x) < 1073741824.0f)) return 0ll;
+    float hi = floorf(x);
+    float frac = x - hi;                                         // exact, in [0,1)
+    uint32_t lo = (uint32_t)(frac * 4294967296.0f);              // truncation
+    return (long long)(int)hi * 4294967296ll + (long long)lo;
+}
+RT_DEV float fixed_mean(long long sum, uint32_t spp) { return (float)((double)sum * 0x1p-32 / (double)spp); }
+
+// A wavefront owns one unit of unit_w x unit_h pixels (8x8, 4x4 or 2x2) and all their samples, cut into
+// work items of `chunk` consecutive samples of one pixel (item i: pixel i % P, run i / P).  A lane traces
+// the paths of its item one after the other, adding their colours in fp32; when the run is complete it
+// adds the run sum to the pixel's accumulator in LDS and takes the next item of the unit.  So every lane
+// stays busy until the unit's items are exhausted, whatever the length of the individual paths -- without
+// this, a lane that owns a pixel of sky (one segment per sample) idles while its neighbour finishes a pixel
+// of glass (tens of segments per sample), and the workgroup that owns the glass sphere sets the frame time.
+//   n_chunks == 1 (RtParams.sample_chunk = 0): one item per pixel, 8x8 unit, one lane per pixel; the sum is
+//     the reference's fp32 fold in sample order (ray.cu:123-129, lib.rs:228-231).
+//   n_chunks  > 1: run sums are accumulated exactly (2^-32 fixed point, 64-bit LDS atomics), so the result
+//     does not depend on which lane traced which run, nor on the unit size.
 // MULTI = false: the whole (padded) sphere list fits the LDS tile; staged once, after which every
-//                wavefront runs on its own until its 64 pixels are finished.
+//                wavefront runs on its own until its unit is finished.
 // MULTI = true : the list is streamed tile by tile; the workgroup moves in lock step, one path
 //                segment per outer iteration.
-// Each lane walks its pixel's samples back to back: when a path ends, the lane starts the pixel's next
-// sample in the following iteration instead of idling until its neighbours' paths end.  Samples are
-// still accumulated in sample order, so the sum is the one the nested loops of ray.cu:125-127 give.
+struct Item {
+    uint32_t x, y, pixel, pix;  // image coordinates, global pixel index (RNG key), index in the unit
+    uint32_t s, s_end;          // current sample and end of the run
+    float band;                 // lib.rs:225-226 reflectance of the column
+};
+
+RT_DEV bool unit_pixel(const RtLaunch& L, uint32_t unit, uint32_t pix, uint32_t& x, uint32_t& ly, uint32_t& y) {
+    uint32_t ux = unit % L.units_x, uy = unit / L.units_x;
+    x = ux * L.unit_w + pix % L.unit_w;
+    ly = uy * L.unit_h + pix / L.unit_w;
+    uint32_t k = ly / L.tile_rows;
+    y = L.row_base + k * L.tile_stride_rows + (ly - k * L.tile_rows);
+    return unit < L.n_units && x < L.width && ly < L.rows_local && y < L.height;
+}
+
 template <bool MULTI>
 RT_DEV void render_body(const Scene& sc, uint32_t* __restrict__ rgba, float4* __restrict__ linear,
                         unsigned long long* __restrict__ segments, const RtCamera& cam, const RtLaunch& L) {
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave_tile = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t unit = blockIdx.x * (blockDim.x >> 6) + wave;
     const uint64_t seed = ((uint64_t)L.seed_hi << 32) | L.seed_lo;
     const uint32_t flags = L.flags;
-
-    uint32_t x, ly, y;
-    const bool valid = map_pixel(L, wave_tile, lane, x, ly, y);
-    const uint32_t pixel = y * L.width + x;
+    const uint32_t P = L.unit_w * L.unit_h;
+    const uint32_t n_items = (unit < L.n_units && L.max_depth > 0u) ? P * L.n_chunks : 0u;
+    const bool exact_sum = L.n_chunks > 1u;
 
     Tile tile = {rt_lds, reinterpret_cast<const float*>(rt_lds + tile_capacity(L))};
+    // per-wavefront accumulators, [3][64] 64-bit words: fixed-point sums (exact_sum) or the fp32 run sum bits
+    unsigned long long* accum = accum_base(L) + wave * 192u;
+    for (uint32_t k = lane; k < 192u; k += 64u) accum[k] = 0ull;
     if (!MULTI) {
         tile = stage_tile(L, sc.geom, sc.rrx, 0u, L.n_padded);
         __syncthreads();
@@ -399,25 +442,48 @@ RT_DEV void render_body(const Scene& sc, uint32_t* __restrict__ rgba, float4* __
 
     Cand cand = cand_list(L);
     Stats st;
-    float band = 0.0f;
-    if (flags & RT_FLAG_BAND_ALBEDO) {                           // lib.rs:225-226
-        uint32_t gi = L.width / 5u;
-        band = 0.1f + 0.2f * (float)(x / (gi ? gi : 1u));
-    }
-
-    const uint32_t spp = (valid && L.max_depth > 0u) ? L.samples_per_pixel : 0u;
-    uint32_t s = 0u, seg = 0u, nb = 0u;
-    unsigned long long nseg = 0ull;
-    V3 total = v3(0.0f, 0.0f, 0.0f), thr = v3(1.0f, 1.0f, 1.0f);
+    Item it;
+    it.x = it.y = it.pixel = it.pix = 0u; it.s = it.s_end = 0u; it.band = 0.0f;
+    uint32_t next = 0u;                                          // next unclaimed item of the unit (wave-uniform)
+    bool need = true, active = false;
+    uint32_t seg = 0u, nb = 0u, nseg = 0u;
+    V3 run = v3(0.0f, 0.0f, 0.0f), thr = v3(1.0f, 1.0f, 1.0f);
     V3 o = v3(0.0f, 0.0f, 0.0f), d = v3(0.0f, 0.0f, 1.0f);
-    if (s < spp) sample_ray(cam, L, seed, x, y, pixel, s, o, d);
 
     for (;;) {
-        const bool active = s < spp;
+        // hand out items: the lanes that need one take consecutive indices
+        const unsigned long long want = __ballot(need && next < n_items);
+        if (want != 0ull) {
+            if (need) {
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(want >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)want, 0u));
+                const uint32_t item = next + rank;
+                if (item < n_items) {
+                    it.pix = item % P;
+                    const uint32_t run_idx = item / P;
+                    uint32_t ly;
+                    const bool valid = unit_pixel(L, unit, it.pix, it.x, ly, it.y);
+                    it.pixel = it.y * L.width + it.x;
+                    it.s = run_idx * L.chunk;
+                    it.s_end = it.s + L.chunk < L.samples_per_pixel ? it.s + L.chunk : L.samples_per_pixel;
+                    if (flags & RT_FLAG_BAND_ALBEDO) {           // lib.rs:225-226
+                        uint32_t gi = L.width / 5u;
+                        it.band = 0.1f + 0.2f * (float)(it.x / (gi ? gi : 1u));
+                    }
+                    if (valid && it.s < it.s_end) {
+                        need = false;
+                        active = true;
+                        run = v3(0.0f, 0.0f, 0.0f);
+                        sample_ray(cam, L, seed, it.x, it.y, it.pixel, it.s, o, d);
+                    }                                            // else: nothing to trace, ask again next round
+                }
+            }
+            next += (uint32_t)__popcll(want);
+        }
+        const bool more = active || next < n_items;
         if (MULTI) {
-            if (!__syncthreads_or(active ? 1 : 0)) break;
+            if (!__syncthreads_or(more ? 1 : 0)) break;
         } else {
-            if (__ballot(active) == 0ull) break;
+            if (__ballot(more) == 0ull) break;
         }
         Best b;
         b.t = L.t_max;
@@ -444,7 +510,7 @@ RT_DEV void render_body(const Scene& sc, uint32_t* __restrict__ rgba, float4* __
                 const float4 al = sc.shade[2 * b.idx + 1];
                 const uint32_t mat = sc.mat[b.idx];
                 HitInfo h = finish_hit(cr, b.t, o, d, flags);
-                Rng g = stream_init(seed, pixel, s, seg + 1u);
+                Rng g = stream_init(seed, it.pixel, it.s, seg + 1u);
                 V3 nd = scatter(mat, al.w, d, h, g, flags, st);
                 o = h.p;
                 d = nd;
@@ -458,8 +524,8 @@ RT_DEV void render_body(const Scene& sc, uint32_t* __restrict__ rgba, float4* __
                 color = v3(0.0f, 0.0f, 0.0f);
             } else {
                 if (flags & RT_FLAG_BAND_ALBEDO) {               // lib.rs:195-205, innermost call outwards
-                    color = sky(d, band);
-                    for (uint32_t k = 0u; k < nb; k++) color = v3(band * color.x, band * color.y, band * color.z);
+                    color = sky(d, it.band);
+                    for (uint32_t k = 0u; k < nb; k++) color = v3(it.band * color.x, it.band * color.y, it.band * color.z);
                 } else {
                     V3 sk = sky(d, 0.5f);
                     color = v3(thr.x * sk.x, thr.y * sk.y, thr.z * sk.z);  // ray.cu:45
@@ -467,27 +533,54 @@ RT_DEV void render_body(const Scene& sc, uint32_t* __restrict__ rgba, float4* __
                 path_done = true;
             }
             if (path_done) {
-                total = vadd(total, color);                      // ray.cu:126, lib.rs:230
-                s++;
+                run = vadd(run, color);                          // ray.cu:126, lib.rs:230
+                it.s++;
                 seg = 0u;
                 nb = 0u;
                 thr = v3(1.0f, 1.0f, 1.0f);
-                if (s < spp) sample_ray(cam, L, seed, x, y, pixel, s, o, d);
+                if (it.s < it.s_end) {
+                    sample_ray(cam, L, seed, it.x, it.y, it.pixel, it.s, o, d);
+                } else {                                         // run complete: hand its sum to the pixel
+                    if (exact_sum) {
+                        atomicAdd(accum + it.pix, (unsigned long long)to_fixed(run.x));
+                        atomicAdd(accum + 64u + it.pix, (unsigned long long)to_fixed(run.y));
+                        atomicAdd(accum + 128u + it.pix, (unsigned long long)to_fixed(run.z));
+                    } else {
+                        accum[it.pix] = __float_as_uint(run.x);
+                        accum[64u + it.pix] = __float_as_uint(run.y);
+                        accum[128u + it.pix] = __float_as_uint(run.z);
+                    }
+                    active = false;
+                    need = true;
+                }
             }
         }
     }
 
-    if (valid) {
-        float fs = (float)L.samples_per_pixel;
-        V3 mean = v3(total.x / fs, total.y / fs, total.z / fs);  // ray.cu:129, lib.rs:231
-        size_t k = (size_t)ly * L.width + x;
-        rgba[k] = quant(mean.x, flags) | (quant(mean.y, flags) << 8) | (quant(mean.z, flags) << 16) | (255u << 24);
-        if (linear) linear[k] = make_float4(mean.x, mean.y, mean.z, 1.0f);
+    // lanes 0..P-1 finish one pixel each: mean, gamma, RGBA8
+    if (lane < P) {
+        uint32_t x, ly, y;
+        if (unit_pixel(L, unit, lane, x, ly, y)) {
+            V3 mean;
+            if (exact_sum) {
+                mean = v3(fixed_mean((long long)accum[lane], L.samples_per_pixel),
+                          fixed_mean((long long)accum[64u + lane], L.samples_per_pixel),
+                          fixed_mean((long long)accum[128u + lane], L.samples_per_pixel));
+            } else {
+                float fs = (float)L.samples_per_pixel;           // ray.cu:129, lib.rs:231
+                mean = v3(__uint_as_float((uint32_t)accum[lane]) / fs, __uint_as_float((uint32_t)accum[64u + lane]) / fs,
+                          __uint_as_float((uint32_t)accum[128u + lane]) / fs);
+            }
+            size_t k = (size_t)ly * L.width + x;
+            rgba[k] = quant(mean.x, flags) | (quant(mean.y, flags) << 8) | (quant(mean.z, flags) << 16) | (255u << 24);
+            if (linear) linear[k] = make_float4(mean.x, mean.y, mean.z, 1.0f);
+        }
     }
     if (segments) {
         // one 64-bit atomic per wavefront
-        for (int off = 32; off > 0; off >>= 1) nseg += __shfl_xor(nseg, off);
-        if (lane == 0u && nseg) atomicAdd(segments, nseg);
+        unsigned long long n64 = nseg;
+        for (int off = 32; off > 0; off >>= 1) n64 += __shfl_xor(n64, off);
+        if (lane == 0u && n64) atomicAdd(segments, n64);
 #ifdef RT_STATS
         for (int w = 1; w < 8; w++) {
             unsigned long long x = st.v[w];

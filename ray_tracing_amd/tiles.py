@@ -49,6 +49,9 @@ def gather_frame(local, height, rank, world, scratch=None, tile_rows=TILE_ROWS):
     if rank == 0 and scratch is None:
         scratch = [torch.empty_like(local) for _ in range(world)]
     dist.gather(local, scratch if rank == 0 else None, dst=0)
+    if local.is_cuda:
+        # the collective is only enqueued; `local` is rewritten by the next render on another stream
+        torch.cuda.current_stream(local.device).synchronize()
     if rank != 0:
         return None
     return assemble(scratch, height, tile_rows)

@@ -31,7 +31,7 @@ class RtCamera(C.Structure):
 class RtParams(C.Structure):
     _fields_ = [("samples_per_pixel", C.c_uint32), ("sample2_per_pixel", C.c_uint32), ("max_depth", C.c_uint32),
                 ("flags", C.c_uint32), ("seed", C.c_uint64), ("t_min", C.c_float), ("t_max", C.c_float),
-                ("block_dim", C.c_uint32), ("reserved", C.c_uint32)]
+                ("block_dim", C.c_uint32), ("sample_chunk", C.c_uint32)]
 
 
 class OrCameraD(C.Structure):

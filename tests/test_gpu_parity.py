@@ -158,6 +158,54 @@ def test_depth_zero_and_empty_scene(oracle, rt, hip):
     assert (hip.primary_hits(cam, rt.DeviceGUI()) == -1).all()
 
 
+@pytest.mark.parametrize("chunk", [1, 4, 7, 64])
+def test_chunked_accumulation_matches_checker(oracle, rt, hip, chunk):
+    """sample_chunk > 0: runs of samples in fp32, run sums added exactly; lanes take runs dynamically.
+    The checker accumulates the same way, so the result is still bit-exact."""
+    sp = rt.scene_book1_final(1)
+    cam = rt.Camera.look_at(16.0 / 9.0, 200, 20.0, (13.0, 2.0, 3.0), (0.0, 0.0, 0.0))
+    p = rt.DeviceGUI(samples_per_pixel=37, max_depth=50, seed=21, sample_chunk=chunk)
+    got, ref = check_render(oracle, hip, cam, sp, p)
+    # against the reference's fp32 fold the difference is rounding only
+    fold = hip.render(cam, rt.DeviceGUI(samples_per_pixel=37, max_depth=50, seed=21), linear=True)
+    assert got["rays"] == fold["rays"]
+    assert np.abs(got["linear"] - fold["linear"]).max() < 2e-6
+    assert psnr(got["rgba"], fold["rgba"]) > 60.0
+
+
+def test_chunked_cpu_defaults_and_ragged_edges(oracle, rt, hip):
+    check_render(oracle, hip, rt.Camera.new_cpu(16.0 / 9.0, 256), rt.scene_cpu_default(), rt.cpu_params(64, 20, seed=0, sample_chunk=4))
+    for width, block in ((250, 64), (67, 1024), (9, 0)):
+        cam = rt.Camera.new(16.0 / 9.0, width)
+        check_render(oracle, hip, cam, rt.scene_gpu_default(),
+                     rt.DeviceGUI(samples_per_pixel=11, max_depth=7, seed=width, block_dim=block, sample_chunk=2))
+    cam = rt.Camera.new(16.0 / 9.0, 100)
+    check_render(oracle, hip, cam, rt.scene_gpu_default(), rt.DeviceGUI(sample2_per_pixel=3, max_depth=5, sample_chunk=2))
+    check_render(oracle, hip, cam, rt.scene_gpu_default(), rt.DeviceGUI(samples_per_pixel=6, max_depth=0, sample_chunk=2))
+
+
+def test_chunked_streaming_kernel(oracle, rt, hip):
+    sp = rt.scene_grid(2, 128)
+    cam = rt.Camera.look_at(16.0 / 9.0, 480, 40.0, (0.0, 30.0, 80.0), (0.0, 0.0, 0.0))
+    check_render(oracle, hip, cam, sp, rt.DeviceGUI(samples_per_pixel=5, max_depth=16, seed=5, sample_chunk=2), row0=130, rows=20)
+
+
+def test_unit_size_does_not_change_the_image(rt, hip, monkeypatch):
+    """The wavefront's pixel unit (8x8 / 4x4 / 2x2) is a scheduling choice: exact accumulation makes the frame
+    identical for all of them."""
+    sp = rt.scene_book1_final(1)
+    cam = rt.Camera.look_at(16.0 / 9.0, 150, 20.0, (13.0, 2.0, 3.0), (0.0, 0.0, 0.0))
+    p = rt.DeviceGUI(samples_per_pixel=24, max_depth=30, seed=8, sample_chunk=2)
+    hip.upload_scene(sp)
+    frames = []
+    for u in ("2", "4", "8"):
+        monkeypatch.setenv("RT_UNIT", u)
+        frames.append(hip.render(cam, p, linear=True))
+    monkeypatch.delenv("RT_UNIT")
+    for f in frames[1:]:
+        assert np.array_equal(f["linear"], frames[0]["linear"]) and f["rays"] == frames[0]["rays"]
+
+
 def test_rows_are_partition_invariant(rt, hip):
     """Any row range renders the same pixels as the full frame (RNG keyed on the global pixel index)."""
     sp = rt.scene_book1_final(1)

@@ -8,6 +8,7 @@ spp = int(sys.argv[2]) if len(sys.argv) > 2 else 16
 depth = int(sys.argv[3]) if len(sys.argv) > 3 else 50
 block = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 scene = sys.argv[5] if len(sys.argv) > 5 else "book1"
+chunk = int(os.environ.get("RT_CHUNK", "0"))
 if scene == "book1":
     sp = rt.scene_book1_final(1); cam = rt.Camera.look_at(16 / 9, width, 20.0, (13, 2, 3), (0, 0, 0))
 elif scene == "grid":
@@ -16,7 +17,7 @@ elif scene == "hall":
     sp = rt.scene_mirror_hall(3, 64); cam = rt.Camera.look_at(16 / 9, width, 90.0, (0, 0, -85), (0, 0, -70))
 else:
     sp = rt.scene_cpu_default(); cam = rt.Camera.new_cpu(16 / 9, width)
-p = rt.cpu_params(spp, depth, block_dim=block) if scene == "cpu" else rt.DeviceGUI(samples_per_pixel=spp, max_depth=depth, seed=1, block_dim=block)
+p = rt.cpu_params(spp, depth, block_dim=block, sample_chunk=chunk) if scene == "cpu" else rt.DeviceGUI(samples_per_pixel=spp, max_depth=depth, seed=1, block_dim=block, sample_chunk=chunk)
 w = rt.HipWorld(0, sp)
 hs = os.environ.get("RT_HSACO")
 if hs:

@@ -1,0 +1,34 @@
+"""Single-GPU estimate of multi-GPU strong scaling: times the render kernel of rank r of `world` (interleaved
+8-row tiles of the 4K book-1 frame) for several r, and reports T1 / (world * max_r T_r)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import ray_tracing_amd as rt
+from ray_tracing_amd import tiles
+
+spp = int(sys.argv[1]) if len(sys.argv) > 1 else 500
+worlds = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [1, 2, 4, 8]
+sp = rt.scene_book1_final(1)
+cam = rt.Camera.look_at(16 / 9, 3840, 20.0, (13, 2, 3), (0, 0, 0))
+p = rt.DeviceGUI(samples_per_pixel=spp, max_depth=50, seed=1, sample_chunk=int(os.environ.get('RT_CHUNK', '0')))
+w = rt.HipWorld(0, sp)
+hs = os.environ.get("RT_HSACO")
+if hs:
+    w.load_module(open(hs, "rb").read())
+H, W = cam.image_height, cam.image_width
+t1 = None
+for world in worlds:
+    buf = tiles.local_buffer(H, W, world, "cuda")
+    torch.cuda.synchronize()
+    res = []
+    for r in sorted(set([0, world // 2, world - 1])):
+        n = len(tiles.tiles_of_rank(H, r, world))
+        w.render_tiles_device(cam, p, tiles.TILE_ROWS, r, world, n, buf.data_ptr())
+        rays, ms = w.render_tiles_device(cam, p, tiles.TILE_ROWS, r, world, n, buf.data_ptr())
+        res.append((r, rays, ms))
+    tmax = max(ms for _, _, ms in res)
+    if world == 1:
+        t1 = tmax
+    eff = t1 / (world * tmax) if t1 else float("nan")
+    print(f"world {world}: " + ", ".join(f"rank {r}: {rays / 1e6:.0f} Mrays {ms:.1f} ms" for r, rays, ms in res) +
+          f" -> est. efficiency {eff * 100:.1f} %", flush=True)
