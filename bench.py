@@ -40,6 +40,8 @@ def parse():
     ap.add_argument("--spp", type=int, default=500)
     ap.add_argument("--depth", type=int, default=50)
     ap.add_argument("--block-dim", type=int, default=0)
+    ap.add_argument("--sample-chunk", type=int, default=8,
+                    help="samples per work item (RtParams.sample_chunk); 0 = the reference's fp32 fold, one lane per pixel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-width", type=int, default=1920)
     ap.add_argument("--cpu-spp", type=int, default=32)
@@ -87,7 +89,8 @@ def main():
     spheres = rt.scene_book1_final(1)
     cam = rt.Camera.look_at(16.0 / 9.0, args.width, 20.0, (13.0, 2.0, 3.0), (0.0, 0.0, 0.0))
     W, H = cam.image_width, cam.image_height
-    params = rt.DeviceGUI(samples_per_pixel=args.spp, max_depth=args.depth, seed=1, block_dim=args.block_dim)
+    params = rt.DeviceGUI(samples_per_pixel=args.spp, max_depth=args.depth, seed=1, block_dim=args.block_dim,
+                          sample_chunk=args.sample_chunk)
     hip = rt.HipWorld(local_rank, spheres)
 
     my_tiles = len(tiles.tiles_of_rank(H, rank, world))
@@ -157,9 +160,9 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"book-1 final scene, {n_sph} spheres, {W}x{H}, {args.spp} spp, max depth {args.depth}, "
-                                   f"jittered sampler, seed 1; frame split into interleaved {TILE_ROWS}-row tiles over "
+                                   f"jittered sampler, seed 1, sample_chunk {args.sample_chunk}; frame split into interleaved {TILE_ROWS}-row tiles over "
                                    f"{world} GPU(s), RCCL gather to rank 0",
-                       "spheres": n_sph, "width": W, "height": H, "spp": args.spp, "max_depth": args.depth,
+                       "spheres": n_sph, "width": W, "height": H, "spp": args.spp, "max_depth": args.depth, "sample_chunk": args.sample_chunk,
                        "segments_per_frame": rays_all / max(1, args.steps), "parallelism": f"rowtiles{world}"},
             "roofline": {"bound": "valu_fp32", "achieved": achieved, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP32_VECTOR_PEAK_TFLOPS, "traffic": traffic,
