@@ -164,10 +164,12 @@ RT_DEV void drain(const Tile& tile, int base, Cand& c, V3 o, V3 d, float a, floa
 // Filter, 10 VALU operations per sphere and lane (+1 to record the outcome):
 //   oc = c - o;  hf = uf.oc;  nf = rr_f - oc.oc;  q = hf*hf + nf;   candidate iff q >= 0
 // with uf = d * (1/sqrt(d.d)) * (1 + 2^-19) and rr_f = r*r * (1 + 2^-17).  q approximates disc/a of the
-// exact test; the two inflations exceed every rounding difference between q and disc/a (each is below
-// 34 * 2^-24 * oc.oc + 7 * 2^-24 * r*r for values in the normal range, see the derivation in the
-// design notes), so disc >= 0 implies q >= 0.  A NaN anywhere yields a candidate or a sphere the exact
-// test rejects as well.  The sign bits of q for up to 32 consecutive spheres are shifted into one
+// exact test, and the two inflations exceed every rounding difference between them.  With e = 2^-24,
+// k = 2^-19, l = 2^-17 and values in the normal range: hf = s*h + err, |err| <= 7.1e(1+k)|oc|, where
+// s = (1+k)(1+r)/|d|, |r| <= 4.5e and h is the exact test's dot product; nf >= ncc + l*rr - 6e(1+l)(rr+oc.oc);
+// the exact test accepts only if h*h >= a(1-e)(oc.oc - rr - 3e(rr+oc.oc)).  Together
+// hf*hf + nf >= oc.oc*(2k - 33.4e) + rr*(l - 2k + 7e) > 0, so disc >= 0 implies q >= 0.  A NaN anywhere
+// yields a candidate or a sphere the exact test rejects as well.  The sign bits of q for up to 32 consecutive spheres are shifted into one
 // register per lane (v_alignbit: miss = miss << 1 | q >> 31), so the scan has no branch and no compare;
 // after each block the few clear bits become entries of the lane's candidate list.
 RT_DEV void scan_tile(const Tile& tile, uint32_t count, int base,
