@@ -77,7 +77,7 @@ RT_DEV float rand01(Rng& g) { return (float)(pcg_next(g) >> 8) * 0x1p-24f; }
 // Rejection in [-1,1)^3, accept p.p <= 1, normalise (lib.rs:31-47); at most 20 tries, then (1,0,0)
 // (library.cu:25-31).
 RT_DEV V3 random_unit_vector(Rng& g, Stats& st) {
-    V3 r = v3(1.0f, 0.0f, 0.0f);
+    V3 p = v3(1.0f, 0.0f, 0.0f);
     bool done = false;
     for (int i = 0; i < 20 && !done; i++) {
         st.add(5, 1u);
@@ -85,10 +85,11 @@ RT_DEV V3 random_unit_vector(Rng& g, Stats& st) {
         float x = fmaf(2.0f, rand01(g), -1.0f);
         float y = fmaf(2.0f, rand01(g), -1.0f);
         float z = fmaf(2.0f, rand01(g), -1.0f);
-        V3 p = v3(x, y, z);
-        if (vdot(p, p) <= 1.0f) { r = vunit(p); done = true; }
+        V3 q = v3(x, y, z);
+        if (vdot(q, q) <= 1.0f) { p = q; done = true; }
     }
-    return r;
+    // normalised once, after the loop, for all lanes together; the fallback (1,0,0) is its own unit vector
+    return vunit(p);
 }
 
 // ---------------------------------------------------------------- closest hit
