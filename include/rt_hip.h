@@ -121,6 +121,10 @@ uint32_t rt_scene_mirror_hall(uint64_t seed, uint32_t n_small, RtSphere *out, ui
 
 /* Binary PPM (P6) of the RGB channels of an RGBA8 frame. */
 int rt_write_ppm(const char *path, const uint8_t *rgba, uint32_t width, uint32_t height);
+/* The format of the reference's checked-in cpu-implementation/image.ppm: "P3", "W H", "255", then one line per
+ * pixel with the three unrounded values 255.999 * linear colour, printed with the shortest digits that round-trip.
+ * `linear` is the W*H*4 float buffer rt_render_rows returns. */
+int rt_write_ppm_p3f(const char *path, const float *linear, uint32_t width, uint32_t height);
 
 #ifdef __cplusplus
 }

@@ -69,6 +69,7 @@ SYMBOLS = {
     "rt_scene_grid": (C.c_uint32, [C.c_uint64, C.c_uint32, _vp, C.c_uint32]),
     "rt_scene_mirror_hall": (C.c_uint32, [C.c_uint64, C.c_uint32, _vp, C.c_uint32]),
     "rt_write_ppm": (C.c_int, [C.c_char_p, _vp, C.c_uint32, C.c_uint32]),
+    "rt_write_ppm_p3f": (C.c_int, [C.c_char_p, _vp, C.c_uint32, C.c_uint32]),
 }
 
 _lib = None

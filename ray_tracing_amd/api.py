@@ -270,3 +270,11 @@ def write_ppm(path, rgba):
     rc = _ffi.lib().rt_write_ppm(str(path).encode(), _ffi.ptr(a), a.shape[1], a.shape[0])
     if rc:
         raise RtError(rc, f"rt_write_ppm({path}) failed")
+
+
+def write_ppm_p3f(path, linear):
+    """The reference's image.ppm format: P3 header, one line of three unrounded 255.999*linear values per pixel."""
+    a = np.ascontiguousarray(linear, np.float32)
+    rc = _ffi.lib().rt_write_ppm_p3f(str(path).encode(), _ffi.ptr(a), a.shape[1], a.shape[0])
+    if rc:
+        raise RtError(rc, f"rt_write_ppm_p3f({path}) failed")

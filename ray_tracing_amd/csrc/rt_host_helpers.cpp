@@ -1,5 +1,6 @@
 // rt_host_helpers.cpp -- the parts of the C-ABI that need no GPU: camera set-up, scene builders,
 // PPM output.  Citations are relative to the upstream repository root.
+#include <charconv>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -248,6 +249,24 @@ int rt_write_ppm(const char* path, const uint8_t* rgba, uint32_t width, uint32_t
             row[3 * x + 0] = p[4 * x + 0]; row[3 * x + 1] = p[4 * x + 1]; row[3 * x + 2] = p[4 * x + 2];
         }
         if (std::fwrite(row.data(), 1, row.size(), f) != row.size()) { std::fclose(f); return RT_ERR_IO; }
+    }
+    return std::fclose(f) == 0 ? 0 : RT_ERR_IO;
+}
+
+int rt_write_ppm_p3f(const char* path, const float* linear, uint32_t width, uint32_t height) {
+    if (!path || !linear || !width || !height) return RT_ERR_INVALID;
+    FILE* f = std::fopen(path, "w");
+    if (!f) return RT_ERR_IO;
+    std::fprintf(f, "P3\n%u %u\n255\n", width, height);
+    char buf[3 * 32 + 4];
+    for (size_t k = 0; k < (size_t)width * height; k++) {
+        char* q = buf;
+        for (int c = 0; c < 3; c++) {
+            double v = 255.999 * (double)linear[4 * k + c];
+            q = std::to_chars(q, q + 32, v).ptr;       // shortest round-trip digits, as Rust's `{}` prints an f64
+            *q++ = c < 2 ? ' ' : '\n';
+        }
+        if (std::fwrite(buf, 1, (size_t)(q - buf), f) != (size_t)(q - buf)) { std::fclose(f); return RT_ERR_IO; }
     }
     return std::fclose(f) == 0 ? 0 : RT_ERR_IO;
 }

@@ -125,3 +125,26 @@ def test_ppm_writer(rt, tmp_path):
     assert np.array_equal(body, img[..., :3])
     with pytest.raises(rt.RtError):
         rt.write_ppm("/nonexistent-dir/x.ppm", img)
+
+
+def test_p3_float_writer_has_the_reference_image_format(rt, tmp_path):
+    """cpu-implementation/image.ppm: `P3`, `256 144`, `255`, then `r g b` lines of unrounded 255.999*colour with
+    shortest round-trip digits (its sky pixels end in `255.999`)."""
+    lin = np.zeros((2, 3, 4), np.float32)
+    lin[..., 2] = 1.0
+    lin[0, 0, :2] = (0.5, 0.25)
+    lin[1, 2, :2] = (np.float32(0.1), 1.0)
+    path = tmp_path / "x.ppm"
+    rt.write_ppm_p3f(path, lin)
+    lines = open(path).read().split("\n")
+    assert lines[:3] == ["P3", "3 2", "255"] and len(lines) == 3 + 6 + 1 and lines[-1] == ""
+    assert lines[3] == "127.9995 63.99975 255.999"
+    vals = [[float(t) for t in l.split()] for l in lines[3:9]]
+    want = 255.999 * lin[..., :3].astype(np.float64).reshape(-1, 3)
+    assert np.array_equal(np.array(vals), want)          # exact: shortest digits round-trip
+    assert lines[8].split()[0] == repr(255.999 * float(np.float32(0.1)))
+
+
+def test_command_line_renderer_is_built():
+    exe = os.path.join(ROOT, "ray_tracing_amd", "csrc", "rt_render")
+    assert os.path.exists(exe) and os.access(exe, os.X_OK)

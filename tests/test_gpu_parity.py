@@ -294,3 +294,35 @@ def test_module_reload(rt, hip):
     assert hip.render(cam, rt.DeviceGUI())["rays"] > 0
     with pytest.raises(rt.RtError):
         hip.load_module(b"\x00" * 128)
+
+
+def test_command_line_renderer_writes_the_same_frame(rt, hip, tmp_path):
+    """tools/rt_render.cpp (C++ host mirror, include/rt_host.hpp) vs the Python mirror: same bytes."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(rt.__file__), "csrc", "rt_render")
+    out, p3f = tmp_path / "cpu.ppm", tmp_path / "cpu_linear.ppm"
+    res = subprocess.run([exe, "--scene", "cpu", "--width", "128", "--spp", "16", "--depth", "20", "--seed", "3",
+                          "--out", str(out), "--p3f", str(p3f)], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stderr
+    assert "Calculation took" in res.stdout
+    cam = rt.Camera.new_cpu(16.0 / 9.0, 128)
+    hip.upload_scene(rt.scene_cpu_default())
+    ref = hip.render(cam, rt.cpu_params(16, 20, seed=3), linear=True)
+    data = open(out, "rb").read()
+    head = b"P6\n128 72\n255\n"
+    assert data.startswith(head)
+    assert np.array_equal(np.frombuffer(data[len(head):], np.uint8).reshape(72, 128, 3), ref["rgba"][..., :3])
+    lines = open(p3f).read().split("\n")
+    assert lines[:3] == ["P3", "128 72", "255"]
+    vals = np.array([[float(t) for t in l.split()] for l in lines[3:3 + 128 * 72]])
+    assert np.array_equal(vals, 255.999 * ref["linear"][..., :3].astype(np.float64).reshape(-1, 3))
+    # the reference GPU app's defaults: 9 spheres, 4x4 grid samples, depth 4
+    res = subprocess.run([exe, "--scene", "gpu", "--width", "160", "--out", str(tmp_path / "gpu.ppm")],
+                         capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stderr
+    hip.upload_scene(rt.scene_gpu_default())
+    ref = hip.render(rt.Camera.new(16.0 / 9.0, 160), rt.DeviceGUI())
+    data = open(tmp_path / "gpu.ppm", "rb").read()
+    head = b"P6\n160 90\n255\n"
+    assert np.array_equal(np.frombuffer(data[len(head):], np.uint8).reshape(90, 160, 3), ref["rgba"][..., :3])

@@ -1,0 +1,67 @@
+// rt_render -- command-line front end: renders one of the built-in scenes on GPU 0 and writes a PPM.
+// It is the headless counterpart of the reference's two window apps (cpu-implementation/src/main.rs,
+// gpu-implementation/src/main.rs): same scenes, cameras and defaults, no window.
+//   rt_render --scene cpu|gpu|book1|grid|hall [--width W] [--spp N | --grid n] [--depth D] [--seed S]
+//             [--chunk C] [--out image.ppm] [--p3f linear.ppm]
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+
+#include "../include/rt_host.hpp"
+
+static const char* arg(int argc, char** argv, const char* name, const char* def) {
+    for (int i = 1; i + 1 < argc; i++) if (!std::strcmp(argv[i], name)) return argv[i + 1];
+    return def;
+}
+
+int main(int argc, char** argv) {
+    try {
+        std::string scene = arg(argc, argv, "--scene", "cpu");
+        uint32_t width = (uint32_t)std::atoi(arg(argc, argv, "--width", scene == "cpu" ? "256" : "1280"));
+        uint32_t depth = (uint32_t)std::atoi(arg(argc, argv, "--depth", scene == "cpu" ? "20" : "4"));
+        uint32_t spp = (uint32_t)std::atoi(arg(argc, argv, "--spp", scene == "cpu" ? "64" : "0"));
+        uint32_t grid = (uint32_t)std::atoi(arg(argc, argv, "--grid", "4"));
+        uint64_t seed = std::strtoull(arg(argc, argv, "--seed", "0"), nullptr, 10);
+        uint32_t chunk = (uint32_t)std::atoi(arg(argc, argv, "--chunk", "0"));
+        std::string out = arg(argc, argv, "--out", "image.ppm");
+        std::string p3f = arg(argc, argv, "--p3f", "");
+
+        rt::World world;
+        rt::Camera cam;
+        RtParams p;
+        if (scene == "cpu") {                                      // cpu-implementation/src/main.rs:16-34
+            world = rt::scene_cpu_default();
+            cam = rt::Camera::create_cpu(16.0 / 9.0, width);
+            p = rt::CpuParams(spp ? spp : 64, depth, seed);
+        } else {
+            if (scene == "gpu") { world = rt::scene_gpu_default(); cam = rt::Camera::create(16.0f / 9.0f, width); }   // gpu main.rs:22-25
+            else if (scene == "book1") { world = rt::scene_book1_final(1); cam = rt::Camera::look_at(16.0f / 9.0f, width, 20.0f, {13, 2, 3}, {0, 0, 0}); }
+            else if (scene == "grid") { world = rt::scene_grid(2, 128); cam = rt::Camera::look_at(16.0f / 9.0f, width, 40.0f, {0, 30, 80}, {0, 0, 0}); }
+            else if (scene == "hall") { world = rt::scene_mirror_hall(3, 64); cam = rt::Camera::look_at(16.0f / 9.0f, width, 90.0f, {0, 0, -85}, {0, 0, -70}); }
+            else { std::fprintf(stderr, "unknown scene %s\n", scene.c_str()); return 2; }
+            p = spp ? rt::JitterParams(spp, depth, seed) : rt::DeviceGUI(grid, depth);
+            p.seed = seed;
+        }
+        p.sample_chunk = chunk;
+
+        rt::HipWorld hip(0, world);
+        std::vector<uint8_t> frame((size_t)cam.image_width() * cam.image_height() * 4);
+        std::vector<float> linear(p3f.empty() ? 0 : frame.size());
+        auto t0 = std::chrono::steady_clock::now();
+        uint64_t rays = hip.render(frame.data(), cam, p, linear.empty() ? nullptr : linear.data());
+        double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        std::printf("Calculation took %.3f ms (kernel %.3f ms): %ux%u, %zu spheres, %u spp, depth %u, %llu ray segments, %.1f Mrays/s\n",
+                    wall * 1e3, hip.last_kernel_ms(), cam.image_width(), cam.image_height(), world.size(), p.samples_per_pixel,
+                    p.max_depth, (unsigned long long)rays, rays / (hip.last_kernel_ms() * 1e3));   // cpu main.rs:62-64 prints the time
+        rt::write_ppm(out, frame, cam.image_width(), cam.image_height());
+        if (!p3f.empty()) {
+            if (int rc = rt_write_ppm_p3f(p3f.c_str(), linear.data(), cam.image_width(), cam.image_height())) throw rt::Error(rc, "rt_write_ppm_p3f failed");
+        }
+        return 0;
+    } catch (const std::exception& e) {
+        std::fprintf(stderr, "rt_render: %s\n", e.what());
+        return 1;
+    }
+}
