@@ -34,9 +34,11 @@ typedef struct RtLaunch {
 
 // spheres per unrolled scan step (8 measured best: 4 is 3 % slower, 16 costs a wave of occupancy and 2 %)
 #define RT_SCAN_UNROLL 8u
-// Spheres staged in LDS at a time: 2048 x 20 B = 40 KiB.  Scenes up to this size are staged once per
-// workgroup; larger ones are streamed through the same buffer tile by tile.
-#define RT_TILE_SPHERES 2048u
+// Spheres staged in LDS at a time: 1024 x 20 B = 20 KiB.  Scenes up to this size are staged once per
+// workgroup; larger ones are streamed through the same buffer tile by tile.  A bigger tile means fewer
+// barriers per path segment but fewer workgroups per CU: on the 16,385-sphere scene 512 and 1024 run at
+// 232 Mrays/s, 2048 (two workgroups per CU) at 169.
+#define RT_TILE_SPHERES 1024u
 // Candidate slots per lane (u16 each, in LDS); a wavefront drains its lists when a lane holds more than
 // RT_CAND_CAP - RT_SCAN_UNROLL, so a scan step can never overflow them.
 #define RT_CAND_CAP 24u
