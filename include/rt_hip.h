@@ -47,7 +47,7 @@ const char *rt_last_error(const rt_ctx *ctx);
  * the reference compiles at run time with NVRTC, here the object is built by hipcc --genco. */
 int rt_load_module(rt_ctx *ctx, const void *image, size_t size);
 
-/* Uploads the sphere list: AoS host spheres -> device arrays (scan data {c, r*r slightly inflated}, exact r*r,
+/* Uploads the sphere list: AoS host spheres -> device arrays (scan-filter data, exact {c, r*r},
  * shading data {c, radius}, {albedo, fuzz|ior}, material tags).  Stands for the scene the reference builds inside its kernel
  * (gpu-implementation/src/cuda/ray.cu:94-106) and for the `world: &[T]` argument of Camera::render
  * (cpu-implementation/src/lib.rs:221). */

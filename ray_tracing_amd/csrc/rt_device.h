@@ -30,11 +30,12 @@ typedef struct RtLaunch {
     uint32_t n_units;          // units_x * ceil(rows_local / unit_h)
     uint32_t chunk;            // samples per work item (= samples_per_pixel when n_chunks == 1)
     uint32_t n_chunks;         // ceil(samples_per_pixel / chunk); 1 = the reference's fp32 fold
+    float    translate[3];     // T of the scan filter: component-wise median of the sphere centres
 } RtLaunch;
 
 // spheres per unrolled scan step (8 measured best: 4 is 3 % slower, 16 costs a wave of occupancy and 2 %)
 #define RT_SCAN_UNROLL 8u
-// Spheres staged in LDS at a time: 1024 x 20 B = 20 KiB.  Scenes up to this size are staged once per
+// Spheres staged in LDS at a time: 1024 x 32 B = 32 KiB.  Scenes up to this size are staged once per
 // workgroup; larger ones are streamed through the same buffer tile by tile.  A bigger tile means fewer
 // barriers per path segment but fewer workgroups per CU: on the 16,385-sphere scene 512 and 1024 run at
 // 232 Mrays/s, 2048 (two workgroups per CU) at 169.

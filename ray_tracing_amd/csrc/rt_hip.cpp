@@ -4,6 +4,7 @@
 // cudarc-based CudaWorld (gpu-implementation/src/ray_tracing.rs:73-211).  Host C++ only.
 #include <hip/hip_runtime_api.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -34,7 +35,8 @@ struct rt_ctx {
     hipModule_t module = nullptr;
     hipFunction_t f_render = nullptr, f_render_stream = nullptr, f_hits = nullptr, f_random = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    void *d_geom = nullptr, *d_rrx = nullptr, *d_shade = nullptr, *d_mat = nullptr;
+    void *d_geom = nullptr, *d_exact = nullptr, *d_shade = nullptr, *d_mat = nullptr;
+    float translate[3] = {0.0f, 0.0f, 0.0f};
     uint32_t n_spheres = 0, n_padded = 0;
     bool have_scene = false;
     void *d_rgba = nullptr, *d_linear = nullptr, *d_hits = nullptr, *d_counter = nullptr;
@@ -153,6 +155,7 @@ RtLaunch make_launch(const rt_ctx* c, const RtCamera* cam, const RtParams* p, ui
         if (env) { int v = std::atoi(env); if (v == 2 || v == 4 || v == 8) u = (uint32_t)v; }
         L.unit_w = L.unit_h = u;
     }
+    for (int k = 0; k < 3; k++) L.translate[k] = c->translate[k];
     L.units_x = (cam->image_width + L.unit_w - 1u) / L.unit_w;
     L.n_units = L.units_x * ((rows_local + L.unit_h - 1u) / L.unit_h);
     return L;
@@ -164,11 +167,11 @@ void launch_geometry(const RtParams* p, uint32_t n_wave_units, unsigned* grid, u
     *grid = (n_wave_units + waves - 1u) / waves;
 }
 
-// Dynamic LDS per workgroup: the sphere tile (float4 + exact r*r per sphere) plus, per wavefront, one
+// Dynamic LDS per workgroup: the sphere tile (filter float4 + exact float4 per sphere) plus, per wavefront, one
 // candidate-list block and one block of pixel accumulators.
 size_t lds_bytes(const rt_ctx* c, unsigned block) {
     uint32_t n = c->n_padded < RT_TILE_SPHERES ? c->n_padded : RT_TILE_SPHERES;
-    return (size_t)n * 20u + (size_t)(block / 64u) * (RT_CAND_CAP * 64u * 2u + 3u * 64u * 8u);
+    return (size_t)n * 32u + (size_t)(block / 64u) * (RT_CAND_CAP * 64u * 2u + 3u * 64u * 8u);
 }
 
 // One render launch into device buffers; blocking; fills last_ms and (optionally) the segment count.
@@ -179,7 +182,7 @@ int launch_render(rt_ctx* c, const RtCamera* cam, const RtParams* p, RtLaunch L,
     void* d_count = rays_out ? c->d_counter : nullptr;
     if (rays_out) RT_HIP(c, hipMemsetAsync(c->d_counter, 0, 64, c->stream));
     RtCamera cam_copy = *cam;
-    void* args[] = {&c->d_geom, &c->d_rrx, &c->d_shade, &c->d_mat, &d_rgba, &d_linear, &d_count, &cam_copy, &L};
+    void* args[] = {&c->d_geom, &c->d_exact, &c->d_shade, &c->d_mat, &d_rgba, &d_linear, &d_count, &cam_copy, &L};
     hipFunction_t f = (c->n_padded <= RT_TILE_SPHERES) ? c->f_render : c->f_render_stream;
     RT_HIP(c, hipEventRecord(c->ev0, c->stream));
     if (grid > 0)
@@ -195,7 +198,7 @@ int launch_hits(rt_ctx* c, const RtCamera* cam, const RtParams* p, RtLaunch L, v
     unsigned grid, block;
     launch_geometry(p, L.n_wave_tiles, &grid, &block);
     RtCamera cam_copy = *cam;
-    void* args[] = {&c->d_geom, &c->d_rrx, &d_hits, &cam_copy, &L};
+    void* args[] = {&c->d_geom, &c->d_exact, &d_hits, &cam_copy, &L};
     if (grid > 0)
         RT_HIP(c, hipModuleLaunchKernel(c->f_hits, grid, 1, 1, block, 1, 1, (unsigned)lds_bytes(c, block), c->stream, args, nullptr));
     RT_HIP(c, hipStreamSynchronize(c->stream));
@@ -238,7 +241,7 @@ void rt_destroy(rt_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    void* bufs[] = {c->d_geom, c->d_rrx, c->d_shade, c->d_mat, c->d_rgba, c->d_linear, c->d_hits, c->d_counter};
+    void* bufs[] = {c->d_geom, c->d_exact, c->d_shade, c->d_mat, c->d_rgba, c->d_linear, c->d_hits, c->d_counter};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -262,48 +265,66 @@ int rt_upload_scene(rt_ctx* c, const RtSphere* spheres, uint32_t n) {
     RT_HIP(c, hipSetDevice(c->device));
     uint32_t n_padded = ((n + RT_SCAN_UNROLL - 1u) / RT_SCAN_UNROLL) * RT_SCAN_UNROLL;
     if (n_padded == 0) n_padded = RT_SCAN_UNROLL;
-    // geom:  {cx, cy, cz, rr_f} per sphere, rr_f = r*r inflated by 2^-17 and rounded up (scan filter)
-    // rrx:   exact r*r per sphere (exact test)
+    // geom:  scan-filter data {c - T, m} per sphere: T = component-wise median of the centres,
+    //        m = r*r(1+2^-17) - |c-T|^2 (1-2^-18), rounded up (see scan_tile in rt_kernels.hip)
+    // exact: {c, r*r} per sphere for the exact test
     // shade: {cx,cy,cz,radius} {albedo rgb, fuzz|ior} per sphere;  mat: material tag per sphere
-    std::vector<float> geom((size_t)n_padded * 4), rrx(n_padded), shade((size_t)n_padded * 8);
+    float T[3] = {0.0f, 0.0f, 0.0f};
+    if (n) {
+        std::vector<float> v(n);
+        for (int k = 0; k < 3; k++) {
+            for (uint32_t i = 0; i < n; i++) v[i] = spheres[i].center[k];
+            std::nth_element(v.begin(), v.begin() + n / 2, v.end());
+            T[k] = std::isfinite(v[n / 2]) ? v[n / 2] : 0.0f;
+        }
+    }
+    std::vector<float> geom((size_t)n_padded * 4), exact((size_t)n_padded * 4), shade((size_t)n_padded * 8);
     std::vector<uint32_t> mat(n_padded);
     for (uint32_t i = 0; i < n_padded; i++) {
         float* g = &geom[4 * (size_t)i];
+        float* x = &exact[4 * (size_t)i];
         float* s = &shade[8 * (size_t)i];
         if (i < n) {
             const RtSphere& sp = spheres[i];
             if (sp.material < RT_MAT_DIFFUSE || sp.material > RT_MAT_DIELECTRIC)
                 return fail(c, RT_ERR_INVALID, "unknown material tag in sphere " + std::to_string(i));
             const float rr = sp.radius * sp.radius;   // radius*radius, library.cu:203 / lib.rs:101
-            g[0] = sp.center[0]; g[1] = sp.center[1]; g[2] = sp.center[2];
-            g[3] = std::nextafter((float)((double)rr * (1.0 + 0x1p-17)), INFINITY);
-            rrx[i] = rr;
+            double cc = 0.0;
+            for (int k = 0; k < 3; k++) {
+                g[k] = (float)((double)sp.center[k] - (double)T[k]);
+                cc += (double)g[k] * (double)g[k];
+                x[k] = sp.center[k];
+            }
+            const double m = (double)rr * (1.0 + 0x1p-17) - cc * (1.0 - 0x1p-18);
+            g[3] = std::nextafter((float)m, INFINITY);
+            x[3] = rr;
             float param = sp.param;
             if (sp.material == RT_MAT_REFLECT) param = param < 1.0f ? param : 1.0f;   // library.cu:144
             s[0] = sp.center[0]; s[1] = sp.center[1]; s[2] = sp.center[2]; s[3] = sp.radius;
             s[4] = sp.albedo[0]; s[5] = sp.albedo[1]; s[6] = sp.albedo[2]; s[7] = param;
             mat[i] = sp.material;
         } else {
-            // padding up to the scan's unroll factor: r*r = -inf makes the filter value -inf, never a candidate
+            // padding up to the scan's unroll factor: m = -inf makes the filter value -inf, never a candidate
             g[0] = g[1] = g[2] = 0.0f; g[3] = -INFINITY;
-            rrx[i] = -INFINITY;
+            x[0] = x[1] = x[2] = 0.0f; x[3] = -INFINITY;
             s[0] = s[1] = s[2] = 0.0f; s[3] = 1.0f;
             s[4] = s[5] = s[6] = s[7] = 0.0f;
             mat[i] = RT_MAT_DIFFUSE;
         }
     }
     size_t bytes = (size_t)n_padded * 16u;
-    void** owned[] = {&c->d_geom, &c->d_rrx, &c->d_shade, &c->d_mat};
+    void** owned[] = {&c->d_geom, &c->d_exact, &c->d_shade, &c->d_mat};
     for (void** p : owned) if (*p) { RT_HIP(c, hipFree(*p)); *p = nullptr; }
     c->have_scene = false;
     RT_HIP(c, hipMalloc(&c->d_geom, bytes));
-    RT_HIP(c, hipMalloc(&c->d_rrx, (size_t)n_padded * 4u));
+    RT_HIP(c, hipMalloc(&c->d_exact, bytes));
     RT_HIP(c, hipMalloc(&c->d_shade, 2 * bytes));
     RT_HIP(c, hipMalloc(&c->d_mat, (size_t)n_padded * 4u));
     RT_HIP(c, hipMemcpy(c->d_geom, geom.data(), bytes, hipMemcpyHostToDevice));
-    RT_HIP(c, hipMemcpy(c->d_rrx, rrx.data(), (size_t)n_padded * 4u, hipMemcpyHostToDevice));
+    RT_HIP(c, hipMemcpy(c->d_exact, exact.data(), bytes, hipMemcpyHostToDevice));
     RT_HIP(c, hipMemcpy(c->d_shade, shade.data(), 2 * bytes, hipMemcpyHostToDevice));
     RT_HIP(c, hipMemcpy(c->d_mat, mat.data(), (size_t)n_padded * 4u, hipMemcpyHostToDevice));
+    for (int k = 0; k < 3; k++) c->translate[k] = T[k];
     c->n_spheres = n;
     c->n_padded = n_padded;
     c->have_scene = true;

@@ -121,9 +121,9 @@ RT_DEV void sphere_terms(float cx, float cy, float cz, float rr, V3 o, V3 d, flo
 }
 
 // LDS sphere tile of one workgroup:
-//   geo[i] = {cx, cy, cz, rr_f}   rr_f = r*r inflated by 2^-17 (scan filter only)
-//   rrx[i] = r*r                  exact, for the exact test
-struct Tile { const float4* geo; const float* rrx; };
+//   geo[i] = {cx - Tx, cy - Ty, cz - Tz, m}   scan filter only (T, m: see scan_tile)
+//   exa[i] = {cx, cy, cz, r*r}                exact test
+struct Tile { const float4* geo; const float4* exa; };
 
 // Per-lane list of candidate spheres of the tile being scanned, kept in LDS as a column of a
 // [RT_CAND_CAP][64] u16 array per wavefront (lane l owns column l, so pushes never conflict).
@@ -142,18 +142,14 @@ RT_DEV void drain(const Tile& tile, int base, Cand& c, V3 o, V3 d, float a, floa
         st.wave(3);
         if (k < c.n) {
             uint32_t i = c.col[k * 64u];
-            float4 g = tile.geo[i];
+            float4 g = tile.exa[i];
             float h, ncc, disc;
-            sphere_terms(g.x, g.y, g.z, tile.rrx[i], o, d, a, h, ncc, disc);
+            sphere_terms(g.x, g.y, g.z, g.w, o, d, a, h, ncc, disc);
             accept_exact(h, ncc, disc, a, t_min, base + (int)i, b);
         }
     }
     c.n = 0u;
 }
-
-#ifndef RT_VARIANT
-#define RT_VARIANT 4
-#endif
 
 // Scan `count` (a multiple of RT_SCAN_UNROLL) spheres staged in LDS; every lane of the wavefront reads
 // the same float4 per sphere.  The scan only has to list, per lane, a SUPERSET of the spheres the exact
@@ -162,24 +158,36 @@ RT_DEV void drain(const Tile& tile, int base, Cand& c, V3 o, V3 d, float a, floa
 // lanes active.  The closest hit does not depend on when a sphere is tested: the accepted root of a
 // sphere is its first root beyond t_min, if below the bound, whatever the bound.
 //
-// Filter, 10 VALU operations per sphere and lane (+1 to record the outcome):
-//   oc = c - o;  hf = uf.oc;  nf = rr_f - oc.oc;  q = hf*hf + nf;   candidate iff q >= 0
-// with uf = d * (1/sqrt(d.d)) * (1 + 2^-19) and rr_f = r*r * (1 + 2^-17).  q approximates disc/a of the
-// exact test, and the two inflations exceed every rounding difference between them.  With e = 2^-24,
-// k = 2^-19, l = 2^-17 and values in the normal range: hf = s*h + err, |err| <= 7.1e(1+k)|oc|, where
-// s = (1+k)(1+r)/|d|, |r| <= 4.5e and h is the exact test's dot product; nf >= ncc + l*rr - 6e(1+l)(rr+oc.oc);
-// the exact test accepts only if h*h >= a(1-e)(oc.oc - rr - 3e(rr+oc.oc)).  Together
-// hf*hf + nf >= oc.oc*(2k - 33.4e) + rr*(l - 2k + 7e) > 0, so disc >= 0 implies q >= 0.  A NaN anywhere
-// yields a candidate or a sphere the exact test rejects as well.  The sign bits of q for up to 32 consecutive spheres are shifted into one
-// register per lane (v_alignbit: miss = miss << 1 | q >> 31), so the scan has no branch and no compare;
-// after each block the few clear bits become entries of the lane's candidate list.
-RT_DEV void scan_tile(const Tile& tile, uint32_t count, int base,
+// Filter: the sphere can only be hit if  Q = r*r - |c-o|^2 + (u.(c-o))^2 >= 0  (u = d/|d|: squared radius
+// minus squared distance from the centre to the ray's line).  Expanded around a scene-wide translation T
+// (c' = c - T per sphere at upload, o' = o - T per ray) this is, per sphere and lane,
+//   t = m + w.c'          (3 fma)   w = 2 o',  m = r*r(1+2^-17) - |c'|^2 (1-2^-18)      [per sphere, upload]
+//   g = e + uf.c'         (3 fma)   uf = d (1/sqrt(d.d)) (1+2^-19),  e = -uf.o'         [per ray]
+//   q = g*g + t           (1 fma)
+//   key = q + k0          (1 add)   k0 = -|o'|^2 (1-2^-18)                              [per ray]
+// 8 VALU operations, +1 to record the sign of key: 9 per sphere, no branch, no compare, no subtraction
+// of the origin from every centre.  The expansion cancels, so its rounding error grows with the
+// magnitudes: below 35 * 2^-24 * (|c'|^2 + |o'|^2) in all (3 roundings of t at magnitude <= (|c'|+|o'|)^2,
+// error of g times 2|g|, the roundings of q, key, k0, e and of the translated c', o').  The three
+// inflations cover it: 2^-18 (|c'|^2 + |o'|^2) = 64 * 2^-24 * (...) for the expansion, and, for the
+// difference between Q and the exact test's disc/a (whose own roundings scale with |c-o|^2 and r*r), the
+// factors 1+2^-19 on uf and 1+2^-17 on r*r: with e = 2^-24 the exact test accepts only if
+// h*h >= a(1-e)(oc.oc - rr - 3e(rr + oc.oc)), and uf.oc = s*h + err with |err| <= 8e|oc|, which gives
+// Q_computed >= oc.oc (2^-18 - 40e) + rr (2^-17 - 2^-18 + 7e) > 0.  So disc >= 0 implies key >= 0.
+// T (the component-wise median of the centres) keeps |c'| and |o'| of the order of the scene's extent
+// instead of its distance from the world origin.  A NaN anywhere yields a candidate or a sphere the exact
+// test rejects as well.  The sign bits of key for up to 32 consecutive spheres are shifted into one
+// register per lane (v_alignbit: miss = miss << 1 | key >> 31); after each block the few clear bits
+// become entries of the lane's candidate list.
+RT_DEV void scan_tile(const Tile& tile, uint32_t count, int base, V3 T,
                       V3 o, V3 d, float a, float t_min, Best& b, Cand& c, Stats& st) {
     st.wave(1);
-#if RT_VARIANT == 4
+    const V3 op = vsub(o, T);
     const float inv_len = (1.0f / sqrtf(a)) * (1.0f + 0x1p-19f);
     const V3 uf = v3(d.x * inv_len, d.y * inv_len, d.z * inv_len);
-#endif
+    const float e = -vdot(uf, op);
+    const V3 w = v3(2.0f * op.x, 2.0f * op.y, 2.0f * op.z);
+    const float k0 = -(vdot(op, op) * (1.0f - 0x1p-18f));
     for (uint32_t blk = 0; blk < count; blk += 32u) {
         const uint32_t k = (count - blk) < 32u ? (count - blk) : 32u;   // spheres in this block, multiple of 8
         uint32_t miss = 0u;                                            // bit j set: sphere blk + (k-1-j) cannot be hit
@@ -189,19 +197,10 @@ RT_DEV void scan_tile(const Tile& tile, uint32_t count, int base,
             for (uint32_t u = 0; u < RT_SCAN_UNROLL; u++) s[u] = tile.geo[blk + i + u];
 #pragma unroll
             for (uint32_t u = 0; u < RT_SCAN_UNROLL; u++) {
-#if RT_VARIANT == 4
-                const float ocx = s[u].x - o.x, ocy = s[u].y - o.y, ocz = s[u].z - o.z;
-                const float hf = fmaf(uf.z, ocz, fmaf(uf.y, ocy, uf.x * ocx));
-                const float nf = fmaf(-ocz, ocz, fmaf(-ocy, ocy, fmaf(-ocx, ocx, s[u].w)));
-                const uint32_t key = __float_as_uint(fmaf(hf, hf, nf));
-#else
-                // exact terms (on the inflated r*r, still a superset) and the sign trick
-                // key = (h & ncc) | disc: clear sign iff disc >= 0 and (h > 0 or ncc > 0); 13 operations
-                float h, n, q;
-                sphere_terms(s[u].x, s[u].y, s[u].z, s[u].w, o, d, a, h, n, q);
-                const uint32_t key = (__float_as_uint(h) & __float_as_uint(n)) | __float_as_uint(q);
-#endif
-                miss = __builtin_amdgcn_alignbit(miss, key, 31u);
+                const float t = fmaf(w.z, s[u].z, fmaf(w.y, s[u].y, fmaf(w.x, s[u].x, s[u].w)));
+                const float g = fmaf(uf.z, s[u].z, fmaf(uf.y, s[u].y, fmaf(uf.x, s[u].x, e)));
+                const float key = fmaf(g, g, t) + k0;
+                miss = __builtin_amdgcn_alignbit(miss, __float_as_uint(key), 31u);
             }
         }
         uint32_t bits = ~miss & (k == 32u ? 0xffffffffu : ((1u << k) - 1u));
@@ -221,8 +220,8 @@ RT_DEV void scan_tile(const Tile& tile, uint32_t count, int base,
 
 // ---------------------------------------------------------------- shading
 struct Scene {
-    const float4* __restrict__ geom;    // {cx, cy, cz, rr_f} per sphere, n_padded entries
-    const float* __restrict__ rrx;      // exact r*r per sphere, n_padded entries
+    const float4* __restrict__ geom;    // filter data {c - T, m} per sphere, n_padded entries
+    const float4* __restrict__ exact;   // {c, r*r} per sphere, n_padded entries
     const float4* __restrict__ shade;   // per sphere two float4: {cx, cy, cz, radius}, {albedo r, g, b, fuzz | ior}
     const uint32_t* __restrict__ mat;   // material tag per sphere
 };
@@ -350,30 +349,28 @@ RT_DEV bool map_pixel(const RtLaunch& L, uint32_t wave_tile, uint32_t lane, uint
     return wave_tile < L.n_wave_tiles && x < L.width && ly < L.rows_local && y < L.height;
 }
 
-// Dynamic LDS: [geo: T float4][rrx: T float][candidate lists: waves x RT_CAND_CAP x 64 u16]
-// [accumulators: waves x 3 x 64 u64], T = min(n_padded, RT_TILE_SPHERES)
+// Dynamic LDS: [geo: S float4][exa: S float4][candidate lists: waves x RT_CAND_CAP x 64 u16]
+// [accumulators: waves x 3 x 64 u64], S = min(n_padded, RT_TILE_SPHERES)
 extern __shared__ float4 rt_lds[];
 
 RT_DEV uint32_t tile_capacity(const RtLaunch& L) { return L.n_padded < RT_TILE_SPHERES ? L.n_padded : RT_TILE_SPHERES; }
 
-RT_DEV Tile stage_tile(const RtLaunch& L, const float4* __restrict__ geom, const float* __restrict__ rrx,
+RT_DEV Tile stage_tile(const RtLaunch& L, const float4* __restrict__ geom, const float4* __restrict__ exact,
                        uint32_t first, uint32_t count) {
     float4* geo = rt_lds;
-    float* rr = reinterpret_cast<float*>(rt_lds + tile_capacity(L));
-    for (uint32_t i = threadIdx.x; i < count; i += blockDim.x) { geo[i] = geom[first + i]; rr[i] = rrx[first + i]; }
-    Tile t = {geo, rr};
+    float4* exa = rt_lds + tile_capacity(L);
+    for (uint32_t i = threadIdx.x; i < count; i += blockDim.x) { geo[i] = geom[first + i]; exa[i] = exact[first + i]; }
+    Tile t = {geo, exa};
     return t;
 }
 
 RT_DEV unsigned long long* accum_base(const RtLaunch& L) {
-    uint32_t cap = tile_capacity(L);
-    uint16_t* cand = reinterpret_cast<uint16_t*>(reinterpret_cast<float*>(rt_lds + cap) + cap);
+    uint16_t* cand = reinterpret_cast<uint16_t*>(rt_lds + 2u * tile_capacity(L));
     return reinterpret_cast<unsigned long long*>(cand + (blockDim.x >> 6) * (RT_CAND_CAP * 64u));
 }
 
 RT_DEV Cand cand_list(const RtLaunch& L) {
-    uint32_t cap = tile_capacity(L);
-    uint16_t* base = reinterpret_cast<uint16_t*>(reinterpret_cast<float*>(rt_lds + cap) + cap);
+    uint16_t* base = reinterpret_cast<uint16_t*>(rt_lds + 2u * tile_capacity(L));
     Cand c;
     c.col = base + (threadIdx.x >> 6) * (RT_CAND_CAP * 64u) + (threadIdx.x & 63u);
     c.n = 0u;
@@ -434,12 +431,13 @@ RT_DEV void render_body(const Scene& sc, uint32_t* __restrict__ rgba, float4* __
     const uint32_t n_items = (unit < L.n_units && L.max_depth > 0u) ? P * L.n_chunks : 0u;
     const bool exact_sum = L.n_chunks > 1u;
 
-    Tile tile = {rt_lds, reinterpret_cast<const float*>(rt_lds + tile_capacity(L))};
+    Tile tile = {rt_lds, rt_lds + tile_capacity(L)};
+    const V3 T = ld3(L.translate);
     // per-wavefront accumulators, [3][64] 64-bit words: fixed-point sums (exact_sum) or the fp32 run sum bits
     unsigned long long* accum = accum_base(L) + wave * 192u;
     for (uint32_t k = lane; k < 192u; k += 64u) accum[k] = 0ull;
     if (!MULTI) {
-        tile = stage_tile(L, sc.geom, sc.rrx, 0u, L.n_padded);
+        tile = stage_tile(L, sc.geom, sc.exact, 0u, L.n_padded);
         __syncthreads();
     }
 
@@ -497,12 +495,12 @@ RT_DEV void render_body(const Scene& sc, uint32_t* __restrict__ rgba, float4* __
                 uint32_t count = L.n_padded - first;
                 if (count > RT_TILE_SPHERES) count = RT_TILE_SPHERES;
                 if (first) __syncthreads();                      // previous tile fully scanned
-                tile = stage_tile(L, sc.geom, sc.rrx, first, count);
+                tile = stage_tile(L, sc.geom, sc.exact, first, count);
                 __syncthreads();
-                if (active) scan_tile(tile, count, (int)first, o, d, a, L.t_min, b, cand, st);
+                if (active) scan_tile(tile, count, (int)first, T, o, d, a, L.t_min, b, cand, st);
             }
         } else {
-            if (active) scan_tile(tile, L.n_padded, 0, o, d, a, L.t_min, b, cand, st);
+            if (active) scan_tile(tile, L.n_padded, 0, T, o, d, a, L.t_min, b, cand, st);
         }
         if (active) {
             nseg++;
@@ -595,23 +593,23 @@ RT_DEV void render_body(const Scene& sc, uint32_t* __restrict__ rgba, float4* __
 }
 
 extern "C" __global__ void __launch_bounds__(1024)
-rt_render(const float4* geom, const float* rrx, const float4* shade, const uint32_t* mat, uint32_t* rgba,
+rt_render(const float4* geom, const float4* exact, const float4* shade, const uint32_t* mat, uint32_t* rgba,
           float4* linear, unsigned long long* segments, RtCamera cam, RtLaunch L) {
-    Scene sc = {geom, rrx, shade, mat};
+    Scene sc = {geom, exact, shade, mat};
     render_body<false>(sc, rgba, linear, segments, cam, L);
 }
 
 extern "C" __global__ void __launch_bounds__(1024)
-rt_render_stream(const float4* geom, const float* rrx, const float4* shade, const uint32_t* mat, uint32_t* rgba,
+rt_render_stream(const float4* geom, const float4* exact, const float4* shade, const uint32_t* mat, uint32_t* rgba,
                  float4* linear, unsigned long long* segments, RtCamera cam, RtLaunch L) {
-    Scene sc = {geom, rrx, shade, mat};
+    Scene sc = {geom, exact, shade, mat};
     render_body<true>(sc, rgba, linear, segments, cam, L);
 }
 
 // ---------------------------------------------------------------- primary-hit index map
 // Closest sphere index (or -1) of the ray through each pixel centre (sub-pixel offset 0).
 extern "C" __global__ void __launch_bounds__(1024)
-rt_primary_hits(const float4* geom, const float* rrx, int32_t* hits, RtCamera cam, RtLaunch L) {
+rt_primary_hits(const float4* geom, const float4* exact, int32_t* hits, RtCamera cam, RtLaunch L) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave_tile = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     uint32_t x, ly, y;
@@ -628,9 +626,9 @@ rt_primary_hits(const float4* geom, const float* rrx, int32_t* hits, RtCamera ca
         uint32_t count = L.n_padded - first;
         if (count > RT_TILE_SPHERES) count = RT_TILE_SPHERES;
         if (first) __syncthreads();
-        Tile tile = stage_tile(L, geom, rrx, first, count);
+        Tile tile = stage_tile(L, geom, exact, first, count);
         __syncthreads();
-        if (valid) scan_tile(tile, count, (int)first, o, d, a, L.t_min, b, cand, st);
+        if (valid) scan_tile(tile, count, (int)first, ld3(L.translate), o, d, a, L.t_min, b, cand, st);
     }
     if (valid) hits[(size_t)ly * L.width + x] = b.idx;
 }

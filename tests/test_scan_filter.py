@@ -1,8 +1,10 @@
 """The scan's conservative filter must never drop a sphere the exact test can accept.
 
-Kernel (rt_kernels.hip, scan_tile):  q = fma(hf, hf, nf),  hf = uf.oc,  nf = rr_f - oc.oc,
-  uf = d * (1/sqrt(d.d)) * (1 + 2^-19),  rr_f = r*r * (1 + 2^-17) rounded up;   candidate iff sign(q) clear.
-Exact test (checker order):            disc = fma(h, h, a*ncc),  h = d.oc,  ncc = r*r - oc.oc;  needs disc >= 0.
+Kernel (rt_kernels.hip, scan_tile), with T the scene translation, c' = fl(c - T), o' = fl(o - T):
+  t = fma(w.z,c'z, fma(w.y,c'y, fma(w.x,c'x, m)))      w = 2 o',  m = r*r(1+2^-17) - |c'|^2 (1-2^-18), rounded up
+  g = fma(uf.z,c'z, fma(uf.y,c'y, fma(uf.x,c'x, e)))   uf = d (1/sqrt(d.d)) (1+2^-19),  e = -uf.o'
+  key = fma(g, g, t) + k0                              k0 = -(o'.o' (1-2^-18));       candidate iff sign(key) clear.
+Exact test (checker order):  disc = fma(h, h, a*ncc),  h = d.oc,  ncc = r*r - oc.oc, oc = c - o;  needs disc >= 0.
 Here both are evaluated in numpy with float32 fma emulated through float64 (products of two float32 are
 exact in float64), on random and adversarial ray/sphere pairs."""
 import numpy as np
@@ -14,31 +16,41 @@ def fma(a, b, c):
     return (a.astype(np.float64) * b.astype(np.float64) + c.astype(np.float64)).astype(f32)
 
 
+def dot(u, v):
+    return fma(u[2], v[2], fma(u[1], v[1], (u[0] * v[0]).astype(f32)))
+
+
 def terms(o, d, c, rr):
     oc = [(c[k] - o[k]).astype(f32) for k in range(3)]
-    a = fma(d[2], d[2], fma(d[1], d[1], (d[0] * d[0]).astype(f32)))
-    h = fma(d[2], oc[2], fma(d[1], oc[1], (d[0] * oc[0]).astype(f32)))
+    a = dot(d, d)
+    h = dot(d, oc)
     ncc = fma(-oc[2], oc[2], fma(-oc[1], oc[1], fma(-oc[0], oc[0], rr)))
     disc = fma(h, h, (a * ncc).astype(f32))
     return oc, a, h, ncc, disc
 
 
-def filt(oc, a, d, rr):
+def filt(o, d, c, rr, a, T):
+    cp = [(c[k].astype(np.float64) - np.float64(T[k])).astype(f32) for k in range(3)]       # upload, in double
+    cc = sum(cp[k].astype(np.float64) ** 2 for k in range(3))
+    m = np.nextafter((rr.astype(np.float64) * (1.0 + 2.0 ** -17) - cc * (1.0 - 2.0 ** -18)).astype(f32), f32(np.inf))
+    op = [(o[k] - f32(T[k])).astype(f32) for k in range(3)]                                 # kernel, per ray
     inv = ((f32(1.0) / np.sqrt(a)).astype(f32) * f32(1.0 + 2.0 ** -19)).astype(f32)
     uf = [(d[k] * inv).astype(f32) for k in range(3)]
-    rr_f = np.nextafter((rr.astype(np.float64) * (1.0 + 2.0 ** -17)).astype(f32), f32(np.inf))
-    hf = fma(uf[2], oc[2], fma(uf[1], oc[1], (uf[0] * oc[0]).astype(f32)))
-    nf = fma(-oc[2], oc[2], fma(-oc[1], oc[1], fma(-oc[0], oc[0], rr_f)))
-    return fma(hf, hf, nf)
+    e = -dot(uf, op)
+    w = [(f32(2.0) * op[k]).astype(f32) for k in range(3)]
+    k0 = -((dot(op, op) * f32(1.0 - 2.0 ** -18)).astype(f32))
+    t = fma(w[2], cp[2], fma(w[1], cp[1], fma(w[0], cp[0], m)))
+    g = fma(uf[2], cp[2], fma(uf[1], cp[1], fma(uf[0], cp[0], e)))
+    return (fma(g, g, t) + k0).astype(f32)
 
 
-def check(o, d, c, r, label):
+def check(o, d, c, r, label, T=(0.0, 0.0, 0.0)):
     o = [x.astype(f32) for x in o]
     d = [x.astype(f32) for x in d]
     c = [x.astype(f32) for x in c]
     rr = (r.astype(f32) * r.astype(f32)).astype(f32)
     oc, a, h, ncc, disc = terms(o, d, c, rr)
-    q = filt(oc, a, d, rr)
+    q = filt(o, d, c, rr, a, [f32(x) for x in T])
     accepted = disc >= 0
     dropped = accepted & np.signbit(q)
     assert accepted.sum() > 0, label
@@ -61,6 +73,7 @@ def test_random_pairs():
     aim = c + unit(rng, n) * r * rng.uniform(0.0, 1.5, n)
     d = (aim - o) * rng.uniform(0.1, 3.0, n)
     check(list(o), list(d), list(c), r, "random")
+    check(list(o), list(d), list(c), r, "random, translated", T=(3.25, -7.5, 11.0))
 
 
 def test_grazing_rays_exactly_at_the_rim():
@@ -93,6 +106,7 @@ def test_huge_ground_sphere_and_origins_on_surfaces():
     d[1] = np.where(rng.random(n) < 0.5, rng.uniform(-1e-3, 1e-3, n), d[1])
     d *= rng.uniform(0.5, 2.0, n)
     check(list(o), list(d), list(c), r, "ground")
+    check(list(o), list(d), list(c), r, "ground, book-scene translation", T=(0.3, 0.2, -0.4))
     # origins on the surface of small spheres (bounce rays), all directions
     c = rng.uniform(-12, 12, (3, n)); r = rng.uniform(0.2, 1.0, n)
     o = c + unit(rng, n) * r * (1.0 + rng.uniform(-2e-7, 2e-7, n))
@@ -103,9 +117,11 @@ def test_extreme_scales():
     rng = np.random.default_rng(4)
     n = 1_000_000
     for scale, dscale in ((1e-3, 1e-3), (1e4, 1e3), (1.0, 1e-6), (1.0, 1e6), (3e5, 1.0)):
+        # (the translation only matters for speed: far from T the slack makes more spheres candidates)
         c = rng.uniform(-20, 20, (3, n)) * scale
         r = rng.uniform(0.05, 2.0, n) * scale
         o = rng.uniform(-25, 25, (3, n)) * scale
         aim = c + unit(rng, n) * r * rng.uniform(0.9, 1.1, n)
         d = (aim - o) / np.linalg.norm(aim - o, axis=0) * dscale
         check(list(o), list(d), list(c), r, f"scale {scale} dir {dscale}")
+        check(list(o + 1000.0 * scale), list(d), list(c + 1000.0 * scale), r, f"scale {scale} dir {dscale}, far from T")
