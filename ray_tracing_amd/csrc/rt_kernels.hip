@@ -161,10 +161,10 @@ RT_DEV void drain(const Tile& tile, int base, Cand& c, V3 o, V3 d, float a, floa
 // Filter: the sphere can only be hit if  Q = r*r - |c-o|^2 + (u.(c-o))^2 >= 0  (u = d/|d|: squared radius
 // minus squared distance from the centre to the ray's line).  Expanded around a scene-wide translation T
 // (c' = c - T per sphere at upload, o' = o - T per ray) this is, per sphere and lane,
-//   t = m + w.c'          (3 fma)   w = 2 o',  m = r*r(1+2^-17) - |c'|^2 (1-2^-18)      [per sphere, upload]
+//   t = k0 + w.c'         (3 fma)   w = 2 o',  k0 = -|o'|^2 (1-2^-18)                   [per ray]
 //   g = e + uf.c'         (3 fma)   uf = d (1/sqrt(d.d)) (1+2^-19),  e = -uf.o'         [per ray]
 //   q = g*g + t           (1 fma)
-//   key = q + k0          (1 add)   k0 = -|o'|^2 (1-2^-18)                              [per ray]
+//   key = q + m           (1 add)   m = r*r(1+2^-17) - |c'|^2 (1-2^-18)                 [per sphere, upload]
 // 8 VALU operations, +1 to record the sign of key: 9 per sphere, no branch, no compare, no subtraction
 // of the origin from every centre.  The expansion cancels, so its rounding error grows with the
 // magnitudes: below 35 * 2^-24 * (|c'|^2 + |o'|^2) in all (3 roundings of t at magnitude <= (|c'|+|o'|)^2,
@@ -179,6 +179,8 @@ RT_DEV void drain(const Tile& tile, int base, Cand& c, V3 o, V3 d, float a, floa
 // test rejects as well.  The sign bits of key for up to 32 consecutive spheres are shifted into one
 // register per lane (v_alignbit: miss = miss << 1 | key >> 31); after each block the few clear bits
 // become entries of the lane's candidate list.
+// (Reading the filter data with scalar loads instead -- wave-uniform global addresses, the four values of a
+// sphere as SGPR operands -- was built and measured 19 % slower than the LDS tile on the 485-sphere scene.)
 RT_DEV void scan_tile(const Tile& tile, uint32_t count, int base, V3 T,
                       V3 o, V3 d, float a, float t_min, Best& b, Cand& c, Stats& st) {
     st.wave(1);
@@ -197,9 +199,9 @@ RT_DEV void scan_tile(const Tile& tile, uint32_t count, int base, V3 T,
             for (uint32_t u = 0; u < RT_SCAN_UNROLL; u++) s[u] = tile.geo[blk + i + u];
 #pragma unroll
             for (uint32_t u = 0; u < RT_SCAN_UNROLL; u++) {
-                const float t = fmaf(w.z, s[u].z, fmaf(w.y, s[u].y, fmaf(w.x, s[u].x, s[u].w)));
+                const float t = fmaf(w.z, s[u].z, fmaf(w.y, s[u].y, fmaf(w.x, s[u].x, k0)));
                 const float g = fmaf(uf.z, s[u].z, fmaf(uf.y, s[u].y, fmaf(uf.x, s[u].x, e)));
-                const float key = fmaf(g, g, t) + k0;
+                const float key = fmaf(g, g, t) + s[u].w;
                 miss = __builtin_amdgcn_alignbit(miss, __float_as_uint(key), 31u);
             }
         }

@@ -1,9 +1,10 @@
 """The scan's conservative filter must never drop a sphere the exact test can accept.
 
 Kernel (rt_kernels.hip, scan_tile), with T the scene translation, c' = fl(c - T), o' = fl(o - T):
-  t = fma(w.z,c'z, fma(w.y,c'y, fma(w.x,c'x, m)))      w = 2 o',  m = r*r(1+2^-17) - |c'|^2 (1-2^-18), rounded up
+  t = fma(w.z,c'z, fma(w.y,c'y, fma(w.x,c'x, k0)))     w = 2 o',  k0 = -(o'.o' (1-2^-18))
   g = fma(uf.z,c'z, fma(uf.y,c'y, fma(uf.x,c'x, e)))   uf = d (1/sqrt(d.d)) (1+2^-19),  e = -uf.o'
-  key = fma(g, g, t) + k0                              k0 = -(o'.o' (1-2^-18));       candidate iff sign(key) clear.
+  key = fma(g, g, t) + m                               m = r*r(1+2^-17) - |c'|^2 (1-2^-18), rounded up;
+  candidate iff sign(key) clear.
 Exact test (checker order):  disc = fma(h, h, a*ncc),  h = d.oc,  ncc = r*r - oc.oc, oc = c - o;  needs disc >= 0.
 Here both are evaluated in numpy with float32 fma emulated through float64 (products of two float32 are
 exact in float64), on random and adversarial ray/sphere pairs."""
@@ -39,9 +40,9 @@ def filt(o, d, c, rr, a, T):
     e = -dot(uf, op)
     w = [(f32(2.0) * op[k]).astype(f32) for k in range(3)]
     k0 = -((dot(op, op) * f32(1.0 - 2.0 ** -18)).astype(f32))
-    t = fma(w[2], cp[2], fma(w[1], cp[1], fma(w[0], cp[0], m)))
+    t = fma(w[2], cp[2], fma(w[1], cp[1], fma(w[0], cp[0], k0)))
     g = fma(uf[2], cp[2], fma(uf[1], cp[1], fma(uf[0], cp[0], e)))
-    return (fma(g, g, t) + k0).astype(f32)
+    return (fma(g, g, t) + m).astype(f32)
 
 
 def check(o, d, c, r, label, T=(0.0, 0.0, 0.0)):
