@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-LIB_PATH = os.environ.get("RT_HIP_LIB", os.path.join(_CSRC, "librt_hip.so"))   # RT_HIP_LIB: use another build of the library
+LIB_PATH = os.environ.get("RT_HIP_LIB") or os.path.join(_CSRC, "librt_hip.so")   # RT_HIP_LIB: use another build of the library
 
 RT_MAT_DIFFUSE, RT_MAT_REFLECT, RT_MAT_DIELECTRIC = 1, 2, 3
 RT_FLAG_SAMPLER_GRID, RT_FLAG_QUANT_ROUND, RT_FLAG_BAND_ALBEDO, RT_FLAG_FLIP_SIGNBIT = 1, 2, 4, 8

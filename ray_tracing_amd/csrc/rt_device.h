@@ -40,8 +40,10 @@ typedef struct RtLaunch {
 // barriers per path segment but fewer workgroups per CU: on the 16,385-sphere scene 512 and 1024 run at
 // 232 Mrays/s, 2048 (two workgroups per CU) at 169.
 #define RT_TILE_SPHERES 1024u
-// Candidate slots per lane (u16 each, in LDS); a wavefront drains its lists when a lane holds more than
-// RT_CAND_CAP - RT_SCAN_UNROLL, so a scan step can never overflow them.
-#define RT_CAND_CAP 24u
+// Candidate slots per lane (u16 each, in LDS); a wavefront drains its lists as soon as one lane's list
+// is full (checked after every push, so a list can never overflow).
+#ifndef RT_CAND_CAP
+#define RT_CAND_CAP 16u
+#endif
 
 #endif

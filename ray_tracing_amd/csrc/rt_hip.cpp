@@ -169,9 +169,9 @@ void launch_geometry(const RtParams* p, uint32_t n_wave_units, unsigned* grid, u
 
 // Dynamic LDS per workgroup: the sphere tile (filter float4 + exact float4 per sphere) plus, per wavefront, one
 // candidate-list block and one block of pixel accumulators.
-size_t lds_bytes(const rt_ctx* c, unsigned block) {
+size_t lds_bytes(const rt_ctx* c, unsigned block, unsigned unit_pixels) {
     uint32_t n = c->n_padded < RT_TILE_SPHERES ? c->n_padded : RT_TILE_SPHERES;
-    return (size_t)n * 32u + (size_t)(block / 64u) * (RT_CAND_CAP * 64u * 2u + 3u * 64u * 8u);
+    return (size_t)n * 32u + (size_t)(block / 64u) * (RT_CAND_CAP * 64u * 2u + 3u * unit_pixels * 8u);
 }
 
 // One render launch into device buffers; blocking; fills last_ms and (optionally) the segment count.
@@ -186,7 +186,7 @@ int launch_render(rt_ctx* c, const RtCamera* cam, const RtParams* p, RtLaunch L,
     hipFunction_t f = (c->n_padded <= RT_TILE_SPHERES) ? c->f_render : c->f_render_stream;
     RT_HIP(c, hipEventRecord(c->ev0, c->stream));
     if (grid > 0)
-        RT_HIP(c, hipModuleLaunchKernel(f, grid, 1, 1, block, 1, 1, (unsigned)lds_bytes(c, block), c->stream, args, nullptr));
+        RT_HIP(c, hipModuleLaunchKernel(f, grid, 1, 1, block, 1, 1, (unsigned)lds_bytes(c, block, L.unit_w * L.unit_h), c->stream, args, nullptr));
     RT_HIP(c, hipEventRecord(c->ev1, c->stream));
     RT_HIP(c, hipStreamSynchronize(c->stream));
     RT_HIP(c, hipEventElapsedTime(&c->last_ms, c->ev0, c->ev1));
@@ -200,7 +200,7 @@ int launch_hits(rt_ctx* c, const RtCamera* cam, const RtParams* p, RtLaunch L, v
     RtCamera cam_copy = *cam;
     void* args[] = {&c->d_geom, &c->d_exact, &d_hits, &cam_copy, &L};
     if (grid > 0)
-        RT_HIP(c, hipModuleLaunchKernel(c->f_hits, grid, 1, 1, block, 1, 1, (unsigned)lds_bytes(c, block), c->stream, args, nullptr));
+        RT_HIP(c, hipModuleLaunchKernel(c->f_hits, grid, 1, 1, block, 1, 1, (unsigned)lds_bytes(c, block, 64u), c->stream, args, nullptr));
     RT_HIP(c, hipStreamSynchronize(c->stream));
     return 0;
 }

@@ -352,7 +352,7 @@ RT_DEV bool map_pixel(const RtLaunch& L, uint32_t wave_tile, uint32_t lane, uint
 }
 
 // Dynamic LDS: [geo: S float4][exa: S float4][candidate lists: waves x RT_CAND_CAP x 64 u16]
-// [accumulators: waves x 3 x 64 u64], S = min(n_padded, RT_TILE_SPHERES)
+// [accumulators: waves x 3 x P u64, P = pixels per unit], S = min(n_padded, RT_TILE_SPHERES)
 extern __shared__ float4 rt_lds[];
 
 RT_DEV uint32_t tile_capacity(const RtLaunch& L) { return L.n_padded < RT_TILE_SPHERES ? L.n_padded : RT_TILE_SPHERES; }
@@ -435,9 +435,9 @@ RT_DEV void render_body(const Scene& sc, uint32_t* __restrict__ rgba, float4* __
 
     Tile tile = {rt_lds, rt_lds + tile_capacity(L)};
     const V3 T = ld3(L.translate);
-    // per-wavefront accumulators, [3][64] 64-bit words: fixed-point sums (exact_sum) or the fp32 run sum bits
-    unsigned long long* accum = accum_base(L) + wave * 192u;
-    for (uint32_t k = lane; k < 192u; k += 64u) accum[k] = 0ull;
+    // per-wavefront accumulators, [3][P] 64-bit words: fixed-point sums (exact_sum) or the fp32 run sum bits
+    unsigned long long* accum = accum_base(L) + wave * (3u * P);
+    for (uint32_t k = lane; k < 3u * P; k += 64u) accum[k] = 0ull;
     if (!MULTI) {
         tile = stage_tile(L, sc.geom, sc.exact, 0u, L.n_padded);
         __syncthreads();
@@ -546,12 +546,12 @@ RT_DEV void render_body(const Scene& sc, uint32_t* __restrict__ rgba, float4* __
                 } else {                                         // run complete: hand its sum to the pixel
                     if (exact_sum) {
                         atomicAdd(accum + it.pix, (unsigned long long)to_fixed(run.x));
-                        atomicAdd(accum + 64u + it.pix, (unsigned long long)to_fixed(run.y));
-                        atomicAdd(accum + 128u + it.pix, (unsigned long long)to_fixed(run.z));
+                        atomicAdd(accum + P + it.pix, (unsigned long long)to_fixed(run.y));
+                        atomicAdd(accum + 2u * P + it.pix, (unsigned long long)to_fixed(run.z));
                     } else {
                         accum[it.pix] = __float_as_uint(run.x);
-                        accum[64u + it.pix] = __float_as_uint(run.y);
-                        accum[128u + it.pix] = __float_as_uint(run.z);
+                        accum[P + it.pix] = __float_as_uint(run.y);
+                        accum[2u * P + it.pix] = __float_as_uint(run.z);
                     }
                     active = false;
                     need = true;
@@ -567,12 +567,12 @@ RT_DEV void render_body(const Scene& sc, uint32_t* __restrict__ rgba, float4* __
             V3 mean;
             if (exact_sum) {
                 mean = v3(fixed_mean((long long)accum[lane], L.samples_per_pixel),
-                          fixed_mean((long long)accum[64u + lane], L.samples_per_pixel),
-                          fixed_mean((long long)accum[128u + lane], L.samples_per_pixel));
+                          fixed_mean((long long)accum[P + lane], L.samples_per_pixel),
+                          fixed_mean((long long)accum[2u * P + lane], L.samples_per_pixel));
             } else {
                 float fs = (float)L.samples_per_pixel;           // ray.cu:129, lib.rs:231
-                mean = v3(__uint_as_float((uint32_t)accum[lane]) / fs, __uint_as_float((uint32_t)accum[64u + lane]) / fs,
-                          __uint_as_float((uint32_t)accum[128u + lane]) / fs);
+                mean = v3(__uint_as_float((uint32_t)accum[lane]) / fs, __uint_as_float((uint32_t)accum[P + lane]) / fs,
+                          __uint_as_float((uint32_t)accum[2u * P + lane]) / fs);
             }
             size_t k = (size_t)ly * L.width + x;
             rgba[k] = quant(mean.x, flags) | (quant(mean.y, flags) << 8) | (quant(mean.z, flags) << 16) | (255u << 24);
