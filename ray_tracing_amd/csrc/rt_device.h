@@ -24,8 +24,10 @@ typedef struct RtLaunch {
     uint32_t tile_stride_rows; // global row distance between consecutive row tiles of this launch
     uint32_t tiles_x;          // 8x8 wave tiles per image row = ceil(width / 8)          (hit-map kernel)
     uint32_t n_wave_tiles;     // tiles_x * ceil(rows_local / 8)
-    // render kernels: one wavefront per unit of unit_w x unit_h pixels, samples cut into runs of `chunk`
-    uint32_t unit_w, unit_h;   // 8x8, 4x4 or 2x2; unit_h divides tile_rows
+    // render kernels: wavefronts take units of unit_w x unit_h pixels, samples cut into runs of `chunk`
+    uint32_t unit_w, unit_h;   // powers of two, unit_w * unit_h <= 64; unit_h divides tile_rows
+    uint32_t unit_shift;       // log2(unit_w)
+    uint32_t unit_pshift;      // log2(unit_w * unit_h)
     uint32_t units_x;          // ceil(width / unit_w)
     uint32_t n_units;          // units_x * ceil(rows_local / unit_h)
     uint32_t chunk;            // samples per work item (= samples_per_pixel when n_chunks == 1)

@@ -145,17 +145,28 @@ RtLaunch make_launch(const rt_ctx* c, const RtCamera* cam, const RtParams* p, ui
     } else {
         L.chunk = p->sample_chunk;
         L.n_chunks = (spp + L.chunk - 1u) / L.chunk;
-        // Unit size only affects scheduling (the sums are exact).  Smaller units even out the load between
-        // wavefronts (a 4K frame split over 8 GPUs leaves ~16 8x8 units per SIMD, whose slowest sets the
-        // time); larger ones give each lane more items to even out the load inside the wavefront.  Measured on
-        // the book scene at 4K: 4x4 is within 2 % of 8x8 on one GPU and 25 % faster on an eighth of the frame.
-        uint32_t u = 4u;
-        if ((uint64_t)u * u * L.n_chunks < 64u * 8u) u = 8u;             // too few items per lane: larger unit
-        const char* env = std::getenv("RT_UNIT");
-        if (env) { int v = std::atoi(env); if (v == 2 || v == 4 || v == 8) u = (uint32_t)v; }
-        L.unit_w = L.unit_h = u;
+        // Unit shape only affects scheduling (the sums are exact).  A wavefront has two units open at a time, so
+        // small units cost nothing inside the wavefront, and they shorten the end of the launch, when the last
+        // units are still running and the other wavefronts have nothing left to take.  Measured on the book
+        // scene at 4K, 500 spp: 4x1, 8x1, 16x1 and 2x2 all run the full frame in 1122-1130 ms; an eighth of the
+        // frame (the share of one of 8 GPUs) takes 146, 151, 166 and 144 ms.  4x1 rather than 2x2: a unit is
+        // written as one 16-byte row segment (2x2: two 8-byte ones, 5x the frame's bytes in HBM writes).
+        // A unit must lie in one row tile: any height does when the rows are contiguous.
+        auto height_ok = [&](uint32_t h) { return tile_stride_rows == tile_rows || tile_rows % h == 0u; };
+        L.unit_w = 4u; L.unit_h = 1u;
+        while (L.unit_w * L.unit_h < 64u && (uint64_t)L.unit_w * L.unit_h * L.n_chunks < 64u * 8u) {   // too few items per lane
+            if (L.unit_h < L.unit_w && height_ok(2u * L.unit_h)) L.unit_h *= 2u; else L.unit_w *= 2u;
+        }
+        const char* env = std::getenv("RT_UNIT");                       // "WxH", for experiments
+        if (env) {
+            unsigned w = 0, h = 0;
+            auto pow2 = [](unsigned v) { return v && !(v & (v - 1u)); };
+            if (std::sscanf(env, "%ux%u", &w, &h) == 2 && pow2(w) && pow2(h) && w * h <= 64u && height_ok(h)) { L.unit_w = w; L.unit_h = h; }
+        }
     }
     for (int k = 0; k < 3; k++) L.translate[k] = c->translate[k];
+    for (L.unit_shift = 0; (1u << L.unit_shift) < L.unit_w; L.unit_shift++) {}
+    for (L.unit_pshift = 0; (1u << L.unit_pshift) < L.unit_w * L.unit_h; L.unit_pshift++) {}
     L.units_x = (cam->image_width + L.unit_w - 1u) / L.unit_w;
     L.n_units = L.units_x * ((rows_local + L.unit_h - 1u) / L.unit_h);
     return L;
@@ -168,10 +179,10 @@ void launch_geometry(const RtParams* p, uint32_t n_wave_units, unsigned* grid, u
 }
 
 // Dynamic LDS per workgroup: the sphere tile (filter float4 + exact float4 per sphere) plus, per wavefront, one
-// candidate-list block and one block of pixel accumulators.
+// candidate-list block and the pixel accumulators of its two open units.
 size_t lds_bytes(const rt_ctx* c, unsigned block, unsigned unit_pixels) {
     uint32_t n = c->n_padded < RT_TILE_SPHERES ? c->n_padded : RT_TILE_SPHERES;
-    return (size_t)n * 32u + (size_t)(block / 64u) * (RT_CAND_CAP * 64u * 2u + 3u * unit_pixels * 8u);
+    return (size_t)n * 32u + (size_t)(block / 64u) * (RT_CAND_CAP * 64u * 2u + 2u * 3u * unit_pixels * 8u);
 }
 
 // One render launch into device buffers; blocking; fills last_ms and (optionally) the segment count.
@@ -179,14 +190,24 @@ int launch_render(rt_ctx* c, const RtCamera* cam, const RtParams* p, RtLaunch L,
                   uint64_t* rays_out) {
     unsigned grid, block;
     launch_geometry(p, L.n_units, &grid, &block);
-    void* d_count = rays_out ? c->d_counter : nullptr;
-    if (rays_out) RT_HIP(c, hipMemsetAsync(c->d_counter, 0, 64, c->stream));
-    RtCamera cam_copy = *cam;
-    void* args[] = {&c->d_geom, &c->d_exact, &c->d_shade, &c->d_mat, &d_rgba, &d_linear, &d_count, &cam_copy, &L};
     hipFunction_t f = (c->n_padded <= RT_TILE_SPHERES) ? c->f_render : c->f_render_stream;
+    const unsigned lds = (unsigned)lds_bytes(c, block, L.unit_w * L.unit_h);
+    // The wavefronts take units from a counter until none are left, so the grid only has to fill the GPU
+    // once: as many workgroups as can be resident, if the frame has more units than that.
+    int resident = 0;
+    RT_HIP(c, hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&resident, f, (int)block, lds));
+    if (resident < 1) return fail(c, RT_ERR_INVALID, "render kernel does not fit a compute unit with this block_dim and scene");
+    const unsigned fill = (unsigned)resident * (unsigned)(c->compute_units > 0 ? c->compute_units : 1);
+    if (grid > fill) grid = fill;
+    // counter block: [0] path segments (+ diagnostics in [1..7]), 64-bit each; byte 64: the unit counter
+    void* d_count = rays_out ? c->d_counter : nullptr;
+    void* d_work = static_cast<char*>(c->d_counter) + 64;
+    RT_HIP(c, hipMemsetAsync(c->d_counter, 0, 128, c->stream));
+    RtCamera cam_copy = *cam;
+    void* args[] = {&c->d_geom, &c->d_exact, &c->d_shade, &c->d_mat, &d_rgba, &d_linear, &d_count, &d_work, &cam_copy, &L};
     RT_HIP(c, hipEventRecord(c->ev0, c->stream));
     if (grid > 0)
-        RT_HIP(c, hipModuleLaunchKernel(f, grid, 1, 1, block, 1, 1, (unsigned)lds_bytes(c, block, L.unit_w * L.unit_h), c->stream, args, nullptr));
+        RT_HIP(c, hipModuleLaunchKernel(f, grid, 1, 1, block, 1, 1, lds, c->stream, args, nullptr));
     RT_HIP(c, hipEventRecord(c->ev1, c->stream));
     RT_HIP(c, hipStreamSynchronize(c->stream));
     RT_HIP(c, hipEventElapsedTime(&c->last_ms, c->ev0, c->ev1));
@@ -231,7 +252,7 @@ int rt_create(int device, rt_ctx** out) {
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail(hip_fail(c, e, "hipStreamCreate"));
     if ((e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess)
         return bail(hip_fail(c, e, "hipEventCreate"));
-    if ((e = hipMalloc(&c->d_counter, 64)) != hipSuccess) return bail(hip_fail(c, e, "hipMalloc"));
+    if ((e = hipMalloc(&c->d_counter, 128)) != hipSuccess) return bail(hip_fail(c, e, "hipMalloc"));
     if ((rc = load_image(c, rt_embedded_hsaco)) != 0) return bail(rc);
     *out = c;
     return 0;

@@ -352,7 +352,7 @@ RT_DEV bool map_pixel(const RtLaunch& L, uint32_t wave_tile, uint32_t lane, uint
 }
 
 // Dynamic LDS: [geo: S float4][exa: S float4][candidate lists: waves x RT_CAND_CAP x 64 u16]
-// [accumulators: waves x 3 x P u64, P = pixels per unit], S = min(n_padded, RT_TILE_SPHERES)
+// [accumulators: waves x 2 slots x 3 x P u64, P = pixels per unit], S = min(n_padded, RT_TILE_SPHERES)
 extern __shared__ float4 rt_lds[];
 
 RT_DEV uint32_t tile_capacity(const RtLaunch& L) { return L.n_padded < RT_TILE_SPHERES ? L.n_padded : RT_TILE_SPHERES; }
@@ -391,53 +391,93 @@ RT_DEV long long to_fixed(float x) {
 }
 RT_DEV float fixed_mean(long long sum, uint32_t spp) { return (float)((double)sum * 0x1p-32 / (double)spp); }
 
-// A wavefront owns one unit of unit_w x unit_h pixels (8x8, 4x4 or 2x2) and all their samples, cut into
-// work items of `chunk` consecutive samples of one pixel (item i: pixel i % P, run i / P).  A lane traces
-// the paths of its item one after the other, adding their colours in fp32; when the run is complete it
-// adds the run sum to the pixel's accumulator in LDS and takes the next item of the unit.  So every lane
-// stays busy until the unit's items are exhausted, whatever the length of the individual paths -- without
-// this, a lane that owns a pixel of sky (one segment per sample) idles while its neighbour finishes a pixel
-// of glass (tens of segments per sample), and the workgroup that owns the glass sphere sets the frame time.
-//   n_chunks == 1 (RtParams.sample_chunk = 0): one item per pixel, 8x8 unit, one lane per pixel; the sum is
-//     the reference's fp32 fold in sample order (ray.cu:123-129, lib.rs:228-231).
+// Work distribution.  The frame (or this launch's rows of it) is cut into units of unit_w x unit_h pixels
+// (8x8, 8x1, ...); a unit's samples are cut into work items of `chunk` consecutive samples of one
+// pixel (item i: pixel i % P, run i / P).  The grid is sized to fill the GPU once; every wavefront takes
+// units from a launch-wide counter until none are left.  A lane traces the paths of its item one after
+// the other, adding their colours in fp32; when the run is complete it adds the run sum to the pixel's
+// accumulator in LDS and takes the next item.  A wavefront keeps two units open: when the items of one
+// are all handed out it starts on the next while the last, longest paths of the first finish, so the
+// lanes stay busy whatever the length of the individual paths -- without this, a lane that owns a pixel
+// of sky (one segment per sample) idles while its neighbour finishes a pixel of glass (tens of segments
+// per sample).  A unit's pixels are written when its last item completes.
+//   n_chunks == 1 (RtParams.sample_chunk = 0): one item per pixel, 8x8 units; the sum is the reference's
+//     fp32 fold in sample order (ray.cu:123-129, lib.rs:228-231), kept by one lane per pixel.
 //   n_chunks  > 1: run sums are accumulated exactly (2^-32 fixed point, 64-bit LDS atomics), so the result
 //     does not depend on which lane traced which run, nor on the unit size.
 // MULTI = false: the whole (padded) sphere list fits the LDS tile; staged once, after which every
-//                wavefront runs on its own until its unit is finished.
+//                wavefront runs on its own.
 // MULTI = true : the list is streamed tile by tile; the workgroup moves in lock step, one path
 //                segment per outer iteration.
 struct Item {
-    uint32_t x, y, pixel, pix;  // image coordinates, global pixel index (RNG key), index in the unit
+    uint32_t x, y, pixel;       // image coordinates, global pixel index (RNG key)
+    uint32_t pix;               // index in the unit's accumulators, + 3*P if the item belongs to slot 1
     uint32_t s, s_end;          // current sample and end of the run
     float band;                 // lib.rs:225-226 reflectance of the column
 };
 
-RT_DEV bool unit_pixel(const RtLaunch& L, uint32_t unit, uint32_t pix, uint32_t& x, uint32_t& ly, uint32_t& y) {
-    uint32_t ux = unit % L.units_x, uy = unit / L.units_x;
-    x = ux * L.unit_w + pix % L.unit_w;
-    ly = uy * L.unit_h + pix / L.unit_w;
-    uint32_t k = ly / L.tile_rows;
-    y = L.row_base + k * L.tile_stride_rows + (ly - k * L.tile_rows);
-    return unit < L.n_units && x < L.width && ly < L.rows_local && y < L.height;
+// One of the two units a wavefront has open (all members wave-uniform).
+struct Slot {
+    bool open;                  // a unit is assigned and not yet written out
+    uint32_t left;              // its items not yet completed
+    uint32_t x0, ly0, y0;       // first pixel: column, local row (output buffer), global row (camera)
+};
+
+RT_DEV Slot open_unit(const RtLaunch& L, uint32_t unit, uint32_t n_items) {
+    Slot u;
+    const uint32_t ux = unit % L.units_x, uy = unit / L.units_x;
+    u.x0 = ux * L.unit_w;
+    u.ly0 = uy * L.unit_h;
+    const uint32_t k = u.ly0 / L.tile_rows;                      // unit_h divides tile_rows: one row tile per unit
+    u.y0 = L.row_base + k * L.tile_stride_rows + (u.ly0 - k * L.tile_rows);
+    u.left = n_items;
+    u.open = true;
+    return u;
+}
+
+// lanes 0..P-1 finish one pixel of the unit each (mean, gamma, RGBA8) and clear its accumulators
+RT_DEV void write_unit(const RtLaunch& L, const Slot& u, unsigned long long* acc, uint32_t lane, bool exact_sum,
+                       uint32_t* __restrict__ rgba, float4* __restrict__ linear) {
+    const uint32_t P = L.unit_w * L.unit_h;
+    if (lane < P) {
+        const uint32_t dx = lane & (L.unit_w - 1u), dy = lane >> L.unit_shift;
+        const uint32_t x = u.x0 + dx, ly = u.ly0 + dy, y = u.y0 + dy;
+        V3 mean;
+        if (exact_sum) {
+            mean = v3(fixed_mean((long long)acc[lane], L.samples_per_pixel),
+                      fixed_mean((long long)acc[P + lane], L.samples_per_pixel),
+                      fixed_mean((long long)acc[2u * P + lane], L.samples_per_pixel));
+        } else {
+            const float fs = (float)L.samples_per_pixel;         // ray.cu:129, lib.rs:231
+            mean = v3(__uint_as_float((uint32_t)acc[lane]) / fs, __uint_as_float((uint32_t)acc[P + lane]) / fs,
+                      __uint_as_float((uint32_t)acc[2u * P + lane]) / fs);
+        }
+        acc[lane] = 0ull; acc[P + lane] = 0ull; acc[2u * P + lane] = 0ull;
+        if (x < L.width && ly < L.rows_local && y < L.height) {
+            const size_t k = (size_t)ly * L.width + x;
+            rgba[k] = quant(mean.x, L.flags) | (quant(mean.y, L.flags) << 8) | (quant(mean.z, L.flags) << 16) | (255u << 24);
+            if (linear) linear[k] = make_float4(mean.x, mean.y, mean.z, 1.0f);
+        }
+    }
 }
 
 template <bool MULTI>
 RT_DEV void render_body(const Scene& sc, uint32_t* __restrict__ rgba, float4* __restrict__ linear,
-                        unsigned long long* __restrict__ segments, const RtCamera& cam, const RtLaunch& L) {
+                        unsigned long long* __restrict__ segments, uint32_t* __restrict__ work,
+                        const RtCamera& cam, const RtLaunch& L) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
-    const uint32_t unit = blockIdx.x * (blockDim.x >> 6) + wave;
     const uint64_t seed = ((uint64_t)L.seed_hi << 32) | L.seed_lo;
     const uint32_t flags = L.flags;
     const uint32_t P = L.unit_w * L.unit_h;
-    const uint32_t n_items = (unit < L.n_units && L.max_depth > 0u) ? P * L.n_chunks : 0u;
+    const uint32_t n_items = L.max_depth > 0u ? P * L.n_chunks : 0u;   // per unit
     const bool exact_sum = L.n_chunks > 1u;
 
     Tile tile = {rt_lds, rt_lds + tile_capacity(L)};
     const V3 T = ld3(L.translate);
-    // per-wavefront accumulators, [3][P] 64-bit words: fixed-point sums (exact_sum) or the fp32 run sum bits
-    unsigned long long* accum = accum_base(L) + wave * (3u * P);
-    for (uint32_t k = lane; k < 3u * P; k += 64u) accum[k] = 0ull;
+    // per wavefront and slot: [3][P] 64-bit words, fixed-point sums (exact_sum) or the fp32 run sum bits
+    unsigned long long* accum = accum_base(L) + wave * (6u * P);
+    for (uint32_t k = lane; k < 6u * P; k += 64u) accum[k] = 0ull;
     if (!MULTI) {
         tile = stage_tile(L, sc.geom, sc.exact, 0u, L.n_padded);
         __syncthreads();
@@ -447,42 +487,77 @@ RT_DEV void render_body(const Scene& sc, uint32_t* __restrict__ rgba, float4* __
     Stats st;
     Item it;
     it.x = it.y = it.pixel = it.pix = 0u; it.s = it.s_end = 0u; it.band = 0.0f;
-    uint32_t next = 0u;                                          // next unclaimed item of the unit (wave-uniform)
+    Slot u0, u1;
+    u0.open = u1.open = false;
+    u0.left = u1.left = 0u;
+    u0.x0 = u0.ly0 = u0.y0 = u1.x0 = u1.ly0 = u1.y0 = 0u;
+    uint32_t cur = 1u;                                           // slot items are handed out from
+    uint32_t next = n_items;                                     // its next unclaimed item; n_items: none left (or none open yet)
+    bool drained = false;                                        // the launch's unit counter has run out
     bool need = true, active = false;
     uint32_t seg = 0u, nb = 0u, nseg = 0u;
     V3 run = v3(0.0f, 0.0f, 0.0f), thr = v3(1.0f, 1.0f, 1.0f);
     V3 o = v3(0.0f, 0.0f, 0.0f), d = v3(0.0f, 0.0f, 1.0f);
 
     for (;;) {
-        // hand out items: the lanes that need one take consecutive indices
-        const unsigned long long want = __ballot(need && next < n_items);
+        // completed units: write their pixels, free the slot
+        if (u0.open && u0.left == 0u) { write_unit(L, u0, accum, lane, exact_sum, rgba, linear); u0.open = false; }
+        if (u1.open && u1.left == 0u) { write_unit(L, u1, accum + 3u * P, lane, exact_sum, rgba, linear); u1.open = false; }
+
+        const unsigned long long want = __ballot(need);
         if (want != 0ull) {
-            if (need) {
-                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(want >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)want, 0u));
-                const uint32_t item = next + rank;
-                if (item < n_items) {
-                    it.pix = item % P;
-                    const uint32_t run_idx = item / P;
-                    uint32_t ly;
-                    const bool valid = unit_pixel(L, unit, it.pix, it.x, ly, it.y);
-                    it.pixel = it.y * L.width + it.x;
-                    it.s = run_idx * L.chunk;
-                    it.s_end = it.s + L.chunk < L.samples_per_pixel ? it.s + L.chunk : L.samples_per_pixel;
-                    if (flags & RT_FLAG_BAND_ALBEDO) {           // lib.rs:225-226
-                        uint32_t gi = L.width / 5u;
-                        it.band = 0.1f + 0.2f * (float)(it.x / (gi ? gi : 1u));
-                    }
-                    if (valid && it.s < it.s_end) {
-                        need = false;
-                        active = true;
-                        run = v3(0.0f, 0.0f, 0.0f);
-                        sample_ray(cam, L, seed, it.x, it.y, it.pixel, it.s, o, d);
-                    }                                            // else: nothing to trace, ask again next round
+            // current unit handed out completely: open the next one in the other slot, once that is free
+            if (next >= n_items && !drained && !(cur ? u0.open : u1.open)) {
+                uint32_t unit = 0u;
+                if (lane == 0u) unit = atomicAdd(work, 1u);
+                unit = (uint32_t)__builtin_amdgcn_readfirstlane((int)unit);
+                if (unit >= L.n_units) {
+                    drained = true;
+                } else {
+                    cur ^= 1u;
+                    next = 0u;
+                    if (cur) u1 = open_unit(L, unit, n_items); else u0 = open_unit(L, unit, n_items);
                 }
             }
-            next += (uint32_t)__popcll(want);
+            if (next < n_items) {
+                // the lanes that need an item take consecutive indices
+                bool skipped = false;
+                if (need) {
+                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(want >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)want, 0u));
+                    const uint32_t item = next + rank;
+                    if (item < n_items) {
+                        const uint32_t pix = item & (P - 1u);
+                        const uint32_t run_idx = item >> L.unit_pshift;
+                        const uint32_t dx = pix & (L.unit_w - 1u), dy = pix >> L.unit_shift;
+                        const uint32_t ly = (cur ? u1.ly0 : u0.ly0) + dy;
+                        it.x = (cur ? u1.x0 : u0.x0) + dx;
+                        it.y = (cur ? u1.y0 : u0.y0) + dy;
+                        it.pix = pix + (cur ? 3u * P : 0u);
+                        it.pixel = it.y * L.width + it.x;
+                        it.s = run_idx * L.chunk;
+                        it.s_end = it.s + L.chunk < L.samples_per_pixel ? it.s + L.chunk : L.samples_per_pixel;
+                        if (flags & RT_FLAG_BAND_ALBEDO) {       // lib.rs:225-226
+                            uint32_t gi = L.width / 5u;
+                            it.band = 0.1f + 0.2f * (float)(it.x / (gi ? gi : 1u));
+                        }
+                        if (it.x < L.width && ly < L.rows_local && it.y < L.height && it.s < it.s_end) {
+                            need = false;
+                            active = true;
+                            run = v3(0.0f, 0.0f, 0.0f);
+                            sample_ray(cam, L, seed, it.x, it.y, it.pixel, it.s, o, d);
+                        } else {
+                            skipped = true;                      // pixel outside the image: nothing to trace
+                        }
+                    }
+                }
+                const uint32_t taken = (uint32_t)__popcll(want);
+                const uint32_t given = taken < n_items - next ? taken : n_items - next;
+                next += given;
+                const uint32_t n_skipped = (uint32_t)__popcll(__ballot(skipped));
+                if (cur) u1.left -= n_skipped; else u0.left -= n_skipped;
+            }
         }
-        const bool more = active || next < n_items;
+        const bool more = active || !drained || next < n_items || u0.open || u1.open;
         if (MULTI) {
             if (!__syncthreads_or(more ? 1 : 0)) break;
         } else {
@@ -504,6 +579,7 @@ RT_DEV void render_body(const Scene& sc, uint32_t* __restrict__ rgba, float4* __
         } else {
             if (active) scan_tile(tile, L.n_padded, 0, T, o, d, a, L.t_min, b, cand, st);
         }
+        bool finished = false;                                   // this lane completed its item in this round
         if (active) {
             nseg++;
             bool path_done;
@@ -555,30 +631,18 @@ RT_DEV void render_body(const Scene& sc, uint32_t* __restrict__ rgba, float4* __
                     }
                     active = false;
                     need = true;
+                    finished = true;
                 }
             }
         }
-    }
-
-    // lanes 0..P-1 finish one pixel each: mean, gamma, RGBA8
-    if (lane < P) {
-        uint32_t x, ly, y;
-        if (unit_pixel(L, unit, lane, x, ly, y)) {
-            V3 mean;
-            if (exact_sum) {
-                mean = v3(fixed_mean((long long)accum[lane], L.samples_per_pixel),
-                          fixed_mean((long long)accum[P + lane], L.samples_per_pixel),
-                          fixed_mean((long long)accum[2u * P + lane], L.samples_per_pixel));
-            } else {
-                float fs = (float)L.samples_per_pixel;           // ray.cu:129, lib.rs:231
-                mean = v3(__uint_as_float((uint32_t)accum[lane]) / fs, __uint_as_float((uint32_t)accum[P + lane]) / fs,
-                          __uint_as_float((uint32_t)accum[2u * P + lane]) / fs);
-            }
-            size_t k = (size_t)ly * L.width + x;
-            rgba[k] = quant(mean.x, flags) | (quant(mean.y, flags) << 8) | (quant(mean.z, flags) << 16) | (255u << 24);
-            if (linear) linear[k] = make_float4(mean.x, mean.y, mean.z, 1.0f);
+        const unsigned long long fin = __ballot(finished);
+        if (fin != 0ull) {
+            const uint32_t n1 = (uint32_t)__popcll(__ballot(finished && it.pix >= 3u * P));
+            u1.left -= n1;
+            u0.left -= (uint32_t)__popcll(fin) - n1;
         }
     }
+
     if (segments) {
         // one 64-bit atomic per wavefront
         unsigned long long n64 = nseg;
@@ -596,16 +660,16 @@ RT_DEV void render_body(const Scene& sc, uint32_t* __restrict__ rgba, float4* __
 
 extern "C" __global__ void __launch_bounds__(1024)
 rt_render(const float4* geom, const float4* exact, const float4* shade, const uint32_t* mat, uint32_t* rgba,
-          float4* linear, unsigned long long* segments, RtCamera cam, RtLaunch L) {
+          float4* linear, unsigned long long* segments, uint32_t* work, RtCamera cam, RtLaunch L) {
     Scene sc = {geom, exact, shade, mat};
-    render_body<false>(sc, rgba, linear, segments, cam, L);
+    render_body<false>(sc, rgba, linear, segments, work, cam, L);
 }
 
 extern "C" __global__ void __launch_bounds__(1024)
 rt_render_stream(const float4* geom, const float4* exact, const float4* shade, const uint32_t* mat, uint32_t* rgba,
-                 float4* linear, unsigned long long* segments, RtCamera cam, RtLaunch L) {
+                 float4* linear, unsigned long long* segments, uint32_t* work, RtCamera cam, RtLaunch L) {
     Scene sc = {geom, exact, shade, mat};
-    render_body<true>(sc, rgba, linear, segments, cam, L);
+    render_body<true>(sc, rgba, linear, segments, work, cam, L);
 }
 
 // ---------------------------------------------------------------- primary-hit index map

@@ -191,14 +191,14 @@ def test_chunked_streaming_kernel(oracle, rt, hip):
 
 
 def test_unit_size_does_not_change_the_image(rt, hip, monkeypatch):
-    """The wavefront's pixel unit (8x8 / 4x4 / 2x2) is a scheduling choice: exact accumulation makes the frame
-    identical for all of them."""
+    """The shape of the pixel units the wavefronts take is a scheduling choice: exact accumulation makes the
+    frame identical for all of them."""
     sp = rt.scene_book1_final(1)
     cam = rt.Camera.look_at(16.0 / 9.0, 150, 20.0, (13.0, 2.0, 3.0), (0.0, 0.0, 0.0))
     p = rt.DeviceGUI(samples_per_pixel=24, max_depth=30, seed=8, sample_chunk=2)
     hip.upload_scene(sp)
     frames = []
-    for u in ("2", "4", "8"):
+    for u in ("8x1", "2x2", "4x1", "4x4", "16x1", "8x8", "64x1", "1x1"):
         monkeypatch.setenv("RT_UNIT", u)
         frames.append(hip.render(cam, p, linear=True))
     monkeypatch.delenv("RT_UNIT")

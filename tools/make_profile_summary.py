@@ -75,4 +75,8 @@ if hbm is not None:
     json.dump({"hbm_bytes_per_launch": hbm, "fetch_size_kib": pmc["FETCH_SIZE"], "write_size_kib": pmc["WRITE_SIZE"],
                "note": "rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in separate passes of bench.py --steps 1; FETCH_SIZE doubled (gfx950 correction)"},
               open(os.path.join(dst, f"{tag}_hbm_traffic.json"), "w"))
+# the bench line of the traced run, with the traffic figure of this run's own PMC passes
+if hbm is not None:
+    bench["roofline"]["traffic"] = hbm
+open(os.path.join(dst, f"{tag}_bench_1gpu.json"), "w").write(json.dumps(bench) + "\n")
 print("\n".join(lines))
