@@ -190,6 +190,39 @@ def test_chunked_streaming_kernel(oracle, rt, hip):
     check_render(oracle, hip, cam, sp, rt.DeviceGUI(samples_per_pixel=5, max_depth=16, seed=5, sample_chunk=2), row0=130, rows=20)
 
 
+def test_headline_frame_full_size(oracle, rt, hip):
+    """The configuration the metric is quoted on, in full: book-1 final scene, 3840x2160, 500 spp, depth 50,
+    sample_chunk 2 (what bench.py times).  The whole frame is rendered once on the GPU; the checker renders
+    three bands of rows of the same frame (the RNG is keyed on the global pixel index, so a band of the full
+    frame is a well-defined sub-problem) and every bit of them must agree.  Size-independent properties on
+    the rest: every pixel finite and opaque, the fold-order render of one band within rounding of it, and
+    the per-band ray counts of separate launches add up inside the frame's count."""
+    sp = rt.scene_book1_final(1)
+    cam = rt.Camera.look_at(16.0 / 9.0, 3840, 20.0, (13.0, 2.0, 3.0), (0.0, 0.0, 0.0))
+    p = rt.DeviceGUI(samples_per_pixel=500, max_depth=50, seed=1, sample_chunk=2)
+    hip.upload_scene(sp)
+    full = hip.render(cam, p, linear=True)
+    assert full["linear"].shape == (2160, 3840, 4) and np.isfinite(full["linear"]).all()
+    assert (full["rgba"][..., 3] == 255).all()
+    assert full["rays"] > 3840 * 2160 * 500 * 2            # 2.88 segments per sample on this scene
+    ocam = oracle.camera_f32_from_rt(cam.block)
+    band_rays = 0
+    for row0 in (301, 1178, 2158):                         # sky + distant spheres, the three big spheres, ground at the bottom edge
+        rgba, lin, seg = oracle.render(ocam, sp, p, row0=row0, rows=2)
+        got_lin = full["linear"][row0:row0 + 2]
+        err = np.abs(got_lin.astype(np.float64) - lin.astype(np.float64)).max()
+        assert err <= TOL_LINEAR
+        assert np.array_equal(got_lin.view(np.uint32), lin.view(np.uint32)), f"rows {row0}..: max abs {err}"
+        assert np.array_equal(full["rgba"][row0:row0 + 2], rgba)
+        part = hip.render(cam, p, row0=row0, rows=2)       # the same band as a launch of its own
+        assert part["rays"] == seg and np.array_equal(part["rgba"], rgba)
+        band_rays += seg
+    assert band_rays < full["rays"]
+    fold = hip.render(cam, rt.DeviceGUI(samples_per_pixel=500, max_depth=50, seed=1), row0=1178, rows=2, linear=True)
+    # the fold rounds after each of its 500 additions (observed difference 4.6e-6), the chunked sum once per pixel
+    assert np.abs(fold["linear"] - full["linear"][1178:1180]).max() < 2e-5
+
+
 def test_unit_size_does_not_change_the_image(rt, hip, monkeypatch):
     """The shape of the pixel units the wavefronts take is a scheduling choice: exact accumulation makes the
     frame identical for all of them."""
