@@ -223,6 +223,37 @@ def test_headline_frame_full_size(oracle, rt, hip):
     assert np.abs(fold["linear"] - full["linear"][1178:1180]).max() < 2e-5
 
 
+def test_c4_full_size(oracle, rt, hip):
+    """16,385-sphere grid at its full 1920x1080, 64 spp (the streaming kernel, 17 LDS tiles per segment): the
+    whole frame on the GPU, one row of it bit-exact against the checker."""
+    sp = rt.scene_grid(2, 128)
+    cam = rt.Camera.look_at(16.0 / 9.0, 1920, 40.0, (0.0, 30.0, 80.0), (0.0, 0.0, 0.0))
+    p = rt.DeviceGUI(samples_per_pixel=64, max_depth=50, seed=1, sample_chunk=2)
+    hip.upload_scene(sp)
+    full = hip.render(cam, p, linear=True)
+    assert np.isfinite(full["linear"]).all() and full["rays"] > 1920 * 1080 * 64 * 3
+    rgba, lin, seg = oracle.render(oracle.camera_f32_from_rt(cam.block), sp, p, row0=640, rows=1)
+    assert np.array_equal(full["linear"][640:641].view(np.uint32), lin.view(np.uint32))
+    assert np.array_equal(full["rgba"][640:641], rgba)
+    assert hip.render(cam, p, row0=640, rows=1)["rays"] == seg
+
+
+def test_c5_full_size(oracle, rt, hip):
+    """Mirror/glass hall at its full 7680x4320, 256 spp, depth 100: the whole frame on the GPU, one row of it
+    bit-exact against the checker."""
+    sp = rt.scene_mirror_hall(3, 64)
+    cam = rt.Camera.look_at(16.0 / 9.0, 7680, 90.0, (0.0, 0.0, -85.0), (0.0, 0.0, -70.0))
+    assert cam.image_height == 4320
+    p = rt.DeviceGUI(samples_per_pixel=256, max_depth=100, seed=1, sample_chunk=2)
+    hip.upload_scene(sp)
+    full = hip.render(cam, p)
+    assert (full["rgba"][..., 3] == 255).all() and full["rays"] > 7680 * 4320 * 256 * 2
+    rgba, lin, seg = oracle.render(oracle.camera_f32_from_rt(cam.block), sp, p, row0=2161, rows=1)
+    assert np.array_equal(full["rgba"][2161:2162], rgba)
+    band = hip.render(cam, p, row0=2161, rows=1, linear=True)
+    assert band["rays"] == seg and np.array_equal(band["linear"].view(np.uint32), lin.view(np.uint32))
+
+
 def test_unit_size_does_not_change_the_image(rt, hip, monkeypatch):
     """The shape of the pixel units the wavefronts take is a scheduling choice: exact accumulation makes the
     frame identical for all of them."""
