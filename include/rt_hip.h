@@ -87,10 +87,13 @@ int rt_show_random(rt_ctx *ctx, uint32_t width, uint32_t height, uint64_t seed, 
 /* Milliseconds the last render kernel took on the GPU (hipEvent pair around the launch). */
 float rt_last_kernel_ms(const rt_ctx *ctx);
 
-/* Diagnostic: the 8 counters of the last render that asked for rays_out.  out[0] = ray segments; slots 1..7 are
- * loop-trip counts that only a code object built with -DRT_STATS fills (scan passes, candidates listed,
- * exact-test rounds, decode rounds, unit-vector rounds, drain calls, reserved).  No counterpart in the reference. */
-int rt_debug_counters(rt_ctx *ctx, uint64_t out[8]);
+/* Diagnostic: the 16 64-bit counters of the last render that asked for rays_out.  out[0] = ray segments;
+ * out[8] = pixel units handed out (+ one failed request per wavefront).  The others are filled only by a code
+ * object built with -DRT_STATS: 1..7 loop-trip counts (scan passes, candidates listed, exact-test rounds,
+ * decode rounds, unit-vector tries, drain calls, unit-vector rounds), 9..15 shader cycles per kernel section
+ * (scan filter, decode, exact tests, hit + scatter, sky / next sample, hand-out, rest).  No counterpart in the
+ * reference. */
+int rt_debug_counters(rt_ctx *ctx, uint64_t out[16]);
 
 /* Name and compute-unit count of the context's GPU. */
 int rt_device_info(const rt_ctx *ctx, char *name, size_t name_size, int *compute_units, int *clock_khz);

@@ -254,7 +254,7 @@ class HipWorld:
         return out
 
     def debug_counters(self):
-        out = (C.c_uint64 * 8)()
+        out = (C.c_uint64 * 16)()
         self._check(self._lib.rt_debug_counters(self._ctx, C.byref(out)))
         return list(out)
 

@@ -422,10 +422,10 @@ int rt_show_random(rt_ctx* c, uint32_t width, uint32_t height, uint64_t seed, in
 
 float rt_last_kernel_ms(const rt_ctx* c) { return c ? c->last_ms : 0.0f; }
 
-int rt_debug_counters(rt_ctx* c, uint64_t out[8]) {
+int rt_debug_counters(rt_ctx* c, uint64_t out[16]) {
     if (!c || !out) return RT_ERR_INVALID;
     RT_HIP(c, hipSetDevice(c->device));
-    RT_HIP(c, hipMemcpy(out, c->d_counter, 64, hipMemcpyDeviceToHost));
+    RT_HIP(c, hipMemcpy(out, c->d_counter, 128, hipMemcpyDeviceToHost));
     return 0;
 }
 

@@ -26,23 +26,34 @@ RT_DEV V3 vunit(V3 v) { float inv = 1.0f / sqrtf(vdot(v, v)); return vscale(v, i
 RT_DEV V3 ld3(const float* p) { return v3(p[0], p[1], p[2]); }
 
 // ---------------------------------------------------------------- diagnostics
-// Built with -DRT_STATS the kernels also count loop trips, summed over the launch.  Slots 1..7 of the
-// counter buffer: [1] scan passes per wavefront, [2] candidates listed (per lane), [3] exact-test rounds
-// per wavefront, [4] decode rounds per wavefront, [5] unit-vector tries per lane, [6] drain calls per
-// wavefront, [7] unit-vector rounds per wavefront.  Without RT_STATS the calls compile to nothing.
+// Built with -DRT_STATS the kernels also count loop trips and shader cycles per section, summed over the
+// launch into the counter block (64-bit words).  [1] scan passes per wavefront, [2] candidates listed (per
+// lane), [3] exact-test rounds per wavefront, [4] decode rounds per wavefront, [5] unit-vector tries per lane,
+// [6] drain calls per wavefront, [7] unit-vector rounds per wavefront; cycles a wavefront spent (s_memtime,
+// including the time its SIMD ran other wavefronts) in [9] the scan filter, [10] decode, [11] exact tests,
+// [12] hit record + scatter, [13] sky / next sample / run flush, [14] unit and item hand-out, [15] the rest
+// of the loop.  Without RT_STATS the calls compile to nothing.
 struct Stats {
 #ifdef RT_STATS
     uint32_t v[8];
-    RT_DEV Stats() { for (int i = 0; i < 8; i++) v[i] = 0u; }
+    unsigned long long cyc[7], last;
+    RT_DEV Stats() { for (int i = 0; i < 8; i++) v[i] = 0u; for (int i = 0; i < 7; i++) cyc[i] = 0ull; last = __builtin_amdgcn_s_memtime(); }
     RT_DEV void add(int which, uint32_t n) { v[which] += n; }
     // counted once per wavefront: by the first lane that is active at the call
     RT_DEV void wave(int which) {
         unsigned long long m = __ballot(1);
         if ((uint32_t)(__ffsll((long long)m) - 1) == (threadIdx.x & 63u)) v[which] += 1u;
     }
+    // cycles since the previous lap go to section `which` (9..15)
+    RT_DEV void lap(int which) {
+        unsigned long long now = __builtin_amdgcn_s_memtime();
+        cyc[which - 9] += now - last;
+        last = now;
+    }
 #else
     RT_DEV void add(int, uint32_t) {}
     RT_DEV void wave(int) {}
+    RT_DEV void lap(int) {}
 #endif
 };
 
@@ -138,6 +149,9 @@ RT_DEV void push(Cand& c, uint32_t idx) {
 // for the extra rounds.
 RT_DEV void drain(const Tile& tile, int base, Cand& c, V3 o, V3 d, float a, float t_min, Best& b, Stats& st) {
     st.wave(6);
+#ifdef RT_EXP_DRAIN2
+    for (int twice = 0; twice < 2; twice++)   // cost experiment: a second pass changes nothing (the bound is strict)
+#endif
     for (uint32_t k = 0; __ballot(k < c.n) != 0ull; k++) {
         st.wave(3);
         if (k < c.n) {
@@ -190,6 +204,7 @@ RT_DEV void scan_tile(const Tile& tile, uint32_t count, int base, V3 T,
     const float e = -vdot(uf, op);
     const V3 w = v3(2.0f * op.x, 2.0f * op.y, 2.0f * op.z);
     const float k0 = -(vdot(op, op) * (1.0f - 0x1p-18f));
+    st.lap(15);
     for (uint32_t blk = 0; blk < count; blk += 32u) {
         const uint32_t k = (count - blk) < 32u ? (count - blk) : 32u;   // spheres in this block, multiple of 8
         uint32_t miss = 0u;                                            // bit j set: sphere blk + (k-1-j) cannot be hit
@@ -205,7 +220,23 @@ RT_DEV void scan_tile(const Tile& tile, uint32_t count, int base, V3 T,
                 miss = __builtin_amdgcn_alignbit(miss, __float_as_uint(key), 31u);
             }
         }
+        st.lap(9);
         uint32_t bits = ~miss & (k == 32u ? 0xffffffffu : ((1u << k) - 1u));
+#ifdef RT_EXP_DECODE2
+        {   // cost experiment: the decode loop once more into the same slots, then forgotten
+            uint32_t bits2 = bits;
+            const uint32_t n0 = c.n;
+            while (__ballot(bits2 != 0u) != 0ull) {
+                if (bits2 != 0u) {
+                    uint32_t pos = 31u - (uint32_t)__clz((int)bits2);
+                    push(c, blk + (k - 1u - pos));
+                    bits2 &= ~(1u << pos);
+                }
+                if (__ballot(c.n >= RT_CAND_CAP) != 0ull) c.n = n0;
+            }
+            c.n = n0;
+        }
+#endif
         while (__ballot(bits != 0u) != 0ull) {
             st.wave(4);
             if (bits != 0u) {
@@ -214,10 +245,12 @@ RT_DEV void scan_tile(const Tile& tile, uint32_t count, int base, V3 T,
                 push(c, blk + (k - 1u - pos));
                 bits &= ~(1u << pos);
             }
-            if (__ballot(c.n >= RT_CAND_CAP) != 0ull) drain(tile, base, c, o, d, a, t_min, b, st);
+            if (__ballot(c.n >= RT_CAND_CAP) != 0ull) { st.lap(10); drain(tile, base, c, o, d, a, t_min, b, st); st.lap(11); }
         }
+        st.lap(10);
     }
     drain(tile, base, c, o, d, a, t_min, b, st);
+    st.lap(11);
 }
 
 // ---------------------------------------------------------------- shading
@@ -259,6 +292,14 @@ RT_DEV V3 sky(V3 d, float blend) {
 // (dielectric choice), then the unit-vector rejection triples.
 RT_DEV V3 scatter(uint32_t mat, float param, V3 d, const HitInfo& h, Rng& g, uint32_t flags, Stats& st) {
     float u_choice = rand01(g);
+#ifdef RT_EXP_UNIT2
+    {   // cost experiment: one more unit vector from a copy of the stream, kept alive and unused
+        Rng g2 = g;
+        g2.state ^= 0x9E3779B97F4A7C15ULL;
+        V3 r2 = random_unit_vector(g2, st);
+        asm volatile("" :: "v"(r2.x), "v"(r2.y), "v"(r2.z));
+    }
+#endif
     V3 ru = random_unit_vector(g, st);
     V3 n = h.n;
     V3 out;
@@ -557,6 +598,7 @@ RT_DEV void render_body(const Scene& sc, uint32_t* __restrict__ rgba, float4* __
                 if (cur) u1.left -= n_skipped; else u0.left -= n_skipped;
             }
         }
+        st.lap(14);
         const bool more = active || !drained || next < n_items || u0.open || u1.open;
         if (MULTI) {
             if (!__syncthreads_or(more ? 1 : 0)) break;
@@ -601,6 +643,7 @@ RT_DEV void render_body(const Scene& sc, uint32_t* __restrict__ rgba, float4* __
                 seg++;
                 path_done = (seg == L.max_depth);                // ray.cu:30-32, lib.rs:190-192
                 color = v3(0.0f, 0.0f, 0.0f);
+                st.lap(12);
             } else {
                 if (flags & RT_FLAG_BAND_ALBEDO) {               // lib.rs:195-205, innermost call outwards
                     color = sky(d, it.band);
@@ -635,6 +678,7 @@ RT_DEV void render_body(const Scene& sc, uint32_t* __restrict__ rgba, float4* __
                 }
             }
         }
+        st.lap(13);
         const unsigned long long fin = __ballot(finished);
         if (fin != 0ull) {
             const uint32_t n1 = (uint32_t)__popcll(__ballot(finished && it.pix >= 3u * P));
@@ -654,6 +698,8 @@ RT_DEV void render_body(const Scene& sc, uint32_t* __restrict__ rgba, float4* __
             for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
             if (lane == 0u && x) atomicAdd(segments + w, x);
         }
+        for (int w = 0; w < 7; w++)
+            if (lane == 0u) atomicAdd(segments + 9 + w, st.cyc[w]);
 #endif
     }
 }

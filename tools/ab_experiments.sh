@@ -1,0 +1,8 @@
+#!/bin/bash
+# Marginal cost of parts of the render loop: code objects that do one part twice (same image), timed on
+# the 4K / 500 spp book frame.  make -C ray_tracing_amd/csrc experiments   first.
+set -e
+for v in "" ray_tracing_amd/csrc/rt_kernels_x_*.hsaco; do
+  echo "== ${v:-baseline}"
+  RT_HSACO=$v RT_CHUNK=2 timeout -k 10 200 python -u tools/quick_bench.py 3840 500 50 2>&1 | tail -2
+done

@@ -23,6 +23,13 @@ hs = os.environ.get("RT_HSACO")
 if hs:
     w.load_module(open(hs, "rb").read())
 print(w.device_info(), hs)
+
+
+def sections(c):
+    names = ["scan", "decode", "exact", "hit+scatter", "sky/next", "hand-out", "rest"]
+    tot = sum(c[9:16]) or 1
+    return ", ".join(f"{n} {100 * v / tot:.1f}%" for n, v in zip(names, c[9:16]))
+
 n = len(sp)
 for it in range(3):
     t0 = time.time()
@@ -32,5 +39,5 @@ for it in range(3):
     flops = r["rays"] * (18 * n + 64)
     print(f"{scene} {cam.image_width}x{cam.image_height} spp={spp} depth={depth} n={n}: rays={r['rays']} "
           f"({r['rays'] / (cam.image_width * cam.image_height * spp):.2f}/sample) kernel {ms:.2f} ms wall {dt * 1e3:.1f} ms "
-          + (f"stats {w.debug_counters()} " if hs and "stats" in hs else "") +
+          + (f"stats {w.debug_counters()[:9]} cycle shares {sections(w.debug_counters())} " if hs and "stats" in hs else "") +
           f"-> {r['rays'] / ms * 1e-3:.1f} Mrays/s, {flops / ms * 1e-9:.2f} TFLOP/s ({flops / ms * 1e-9 / 157.3 * 100:.1f}% of 157.3)", flush=True)
