@@ -28,8 +28,12 @@ extern "C" {
 #define RT_ERR_NO_MODULE 10002  /* no code object loaded */
 #define RT_ERR_NO_SCENE  10003  /* rt_upload_scene not called yet */
 #define RT_ERR_IO        10004  /* file output failed */
+#define RT_ERR_COMM      10005  /* RCCL could not be loaded or reported an error */
 
 typedef struct rt_ctx rt_ctx;
+
+/* Number of GPUs this process can use (CudaContext::new(0) assumes one, ray_tracing.rs:107). */
+int rt_device_count(int *count);
 
 /* Creates a context on GPU `device`, its stream, and loads the embedded code object.
  * Stands for CudaWorld::new (ray_tracing.rs:106-127); failures are returned, not panics. */
@@ -74,6 +78,31 @@ int rt_render_rows(rt_ctx *ctx, const RtCamera *cam, const RtParams *params, uin
 int rt_render_tiles_device(rt_ctx *ctx, const RtCamera *cam, const RtParams *params, uint32_t tile_rows,
                            uint32_t first_tile, uint32_t tile_stride, uint32_t n_tiles,
                            void *d_rgba, void *d_linear, uint64_t *rays_out);
+
+/* ---- one frame over the GPUs of a node, gathered to rank 0 with RCCL over xGMI -------------------------
+ * One context per GPU and rank (one process per GPU, or one host thread per GPU).  The reference renders
+ * on one GPU into a host frame the caller owns (CudaWorld::render, ray_tracing.rs:163-210);
+ * rt_render_frame_sharded keeps that shape: every rank calls it with the same camera and parameters, and
+ * rank 0's frame_out receives the whole frame.  RCCL is loaded at first use (environment RT_RCCL_LIB names
+ * the library; default librccl.so.1), so single-GPU users do not need it. */
+#define RT_COMM_ID_BYTES 128
+/* Rank 0: a fresh communicator id (ncclGetUniqueId); hand the bytes to the other ranks by any means. */
+int rt_comm_id(uint8_t id[RT_COMM_ID_BYTES]);
+/* Every rank: join the communicator (ncclCommInitRank on the context's GPU).  Collective. */
+int rt_comm_init(rt_ctx *ctx, const uint8_t id[RT_COMM_ID_BYTES], uint32_t world, uint32_t rank);
+/* Collective.  The frame is dealt out as interleaved tiles of tile_rows rows (a multiple of 8): rank r renders
+ * tiles r, r+world, ...; the tile buffers travel to rank 0 (grouped ncclSend/ncclRecv on the context's
+ * stream), a copy kernel puts them in image order, and rank 0's frame_out (H*W*4 bytes, host) gets the RGBA8
+ * frame -- bit-identical to rt_render_rows on one GPU.  frame_out is ignored on the other ranks.  rays_out
+ * (may be NULL) receives this rank's own segment count.  A context without rt_comm_init is rank 0 of 1. */
+int rt_render_frame_sharded(rt_ctx *ctx, const RtCamera *cam, const RtParams *params, uint32_t tile_rows,
+                            uint8_t *frame_out, uint64_t *rays_out);
+/* The copy kernel of the gather by itself, for hosts that move the tile buffers with a transport of their own
+ * (e.g. torch.distributed): d_gathered holds world buffers back to back, each ceil(ceil(H/tile_rows)/world)
+ * * tile_rows rows of W RGBA8 pixels as rt_render_tiles_device fills them for rank 0, 1, ...; d_frame receives
+ * H*W*4 bytes in image order.  Both are device pointers on the context's GPU.  Blocking. */
+int rt_assemble_tiles(rt_ctx *ctx, const void *d_gathered, uint32_t width, uint32_t height, uint32_t tile_rows,
+                      uint32_t world, void *d_frame);
 
 /* Closest-hit index map only (no shading).  The reference has no such output; it is the integer
  * result of hit_world (ray.cu:1-18) / `[T]::hit` (lib.rs:127-135) for the first segment. */

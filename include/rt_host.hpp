@@ -143,6 +143,22 @@ public:
         check(rt_show_random(ctx_, w, h, seed, norm ? 1 : 0, frame.data()));
         return frame;
     }
+    // One frame over several GPUs (one HipWorld per GPU and rank): rank 0 makes an id, every rank joins, then
+    // all call render_sharded; rank 0's frame holds the result.
+    static std::vector<uint8_t> comm_id() {
+        std::vector<uint8_t> id(RT_COMM_ID_BYTES);
+        if (int rc = rt_comm_id(id.data())) throw Error(rc, rt_last_error(nullptr));
+        return id;
+    }
+    void comm_init(const std::vector<uint8_t>& id, uint32_t world, uint32_t rank) {
+        if (id.size() != RT_COMM_ID_BYTES) throw Error(RT_ERR_INVALID, "communicator id must be RT_COMM_ID_BYTES long");
+        check(rt_comm_init(ctx_, id.data(), world, rank));
+    }
+    uint64_t render_sharded(uint8_t* frame, const Camera& cam, const RtParams& p, uint32_t tile_rows = 8) {
+        uint64_t rays = 0;
+        check(rt_render_frame_sharded(ctx_, &cam.block, &p, tile_rows, frame, &rays));
+        return rays;
+    }
     float last_kernel_ms() const { return rt_last_kernel_ms(ctx_); }
     rt_ctx* raw() { return ctx_; }
 

@@ -46,6 +46,7 @@ assert C.sizeof(RtParams) == 40
 _vp = C.c_void_p
 _ctx = C.c_void_p
 SYMBOLS = {
+    "rt_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "rt_create": (C.c_int, [C.c_int, C.POINTER(_ctx)]),
     "rt_destroy": (None, [_ctx]),
     "rt_last_error": (C.c_char_p, [_ctx]),
@@ -55,6 +56,10 @@ SYMBOLS = {
                                  _vp, _vp, _vp, C.POINTER(C.c_uint64)]),
     "rt_render_tiles_device": (C.c_int, [_ctx, C.POINTER(RtCamera), C.POINTER(RtParams), C.c_uint32, C.c_uint32,
                                          C.c_uint32, C.c_uint32, _vp, _vp, C.POINTER(C.c_uint64)]),
+    "rt_comm_id": (C.c_int, [_vp]),
+    "rt_comm_init": (C.c_int, [_ctx, _vp, C.c_uint32, C.c_uint32]),
+    "rt_render_frame_sharded": (C.c_int, [_ctx, C.POINTER(RtCamera), C.POINTER(RtParams), C.c_uint32, _vp, C.POINTER(C.c_uint64)]),
+    "rt_assemble_tiles": (C.c_int, [_ctx, _vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _vp]),
     "rt_primary_hits": (C.c_int, [_ctx, C.POINTER(RtCamera), C.POINTER(RtParams), C.c_uint32, C.c_uint32, _vp]),
     "rt_show_random": (C.c_int, [_ctx, C.c_uint32, C.c_uint32, C.c_uint64, C.c_int, _vp]),
     "rt_last_kernel_ms": (C.c_float, [_ctx]),
@@ -82,9 +87,13 @@ def _share_hip_runtime_with_torch():
     spec = importlib.util.find_spec("torch")
     if spec is None or not spec.origin:
         return
-    hip = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    libdir = os.path.join(os.path.dirname(spec.origin), "lib")
+    hip = os.path.join(libdir, "libamdhip64.so")
     if os.path.exists(hip):
         C.CDLL(hip, mode=C.RTLD_GLOBAL)
+        rccl = os.path.join(libdir, "librccl.so")
+        if os.path.exists(rccl):                       # the RCCL that goes with that runtime (rt_comm_* load it lazily)
+            os.environ.setdefault("RT_RCCL_LIB", rccl)
 
 
 def lib():

@@ -240,6 +240,43 @@ class HipWorld:
                                                      C.c_void_p(d_linear) if d_linear else None, C.byref(rays)))
         return rays.value, self._lib.rt_last_kernel_ms(self._ctx)
 
+    def assemble_tiles(self, d_gathered, width, height, tile_rows, world, d_frame):
+        """Gathered tile buffers of `world` ranks (device address) -> frame in image order (device address)."""
+        self._check(self._lib.rt_assemble_tiles(self._ctx, C.c_void_p(d_gathered), width, height, tile_rows, world,
+                                                C.c_void_p(d_frame)))
+
+    @staticmethod
+    def device_count():
+        n = C.c_int(0)
+        rc = _ffi.lib().rt_device_count(C.byref(n))
+        if rc != 0:
+            raise RtError(rc, (_ffi.lib().rt_last_error(None) or b"").decode())
+        return n.value
+
+    @staticmethod
+    def comm_id():
+        """A fresh RCCL communicator id (128 bytes); rank 0 creates it and hands it to the other ranks."""
+        buf = (C.c_uint8 * 128)()
+        rc = _ffi.lib().rt_comm_id(C.byref(buf))
+        if rc != 0:
+            raise RtError(rc, (_ffi.lib().rt_last_error(None) or b"").decode())
+        return bytes(buf)
+
+    def comm_init(self, comm_id, world, rank):
+        """Join the communicator as rank `rank` of `world` (collective over the ranks' contexts)."""
+        buf = (C.c_uint8 * 128).from_buffer_copy(comm_id)
+        self._check(self._lib.rt_comm_init(self._ctx, C.byref(buf), world, rank))
+
+    def render_frame_sharded(self, camera, params, tile_rows=8):
+        """Collective: this rank renders its interleaved row tiles; rank 0 returns the assembled RGBA8 frame
+        (the other ranks return None for it).  A context that never joined a communicator is rank 0 of 1."""
+        W, H = camera.image_width, camera.image_height
+        frame = np.empty((H, W, 4), np.uint8)
+        rays = C.c_uint64(0)
+        self._check(self._lib.rt_render_frame_sharded(self._ctx, C.byref(camera.block), C.byref(params), tile_rows,
+                                                      _ffi.ptr(frame), C.byref(rays)))
+        return {"rgba": frame, "rays": rays.value, "kernel_ms": self._lib.rt_last_kernel_ms(self._ctx)}
+
     def primary_hits(self, camera, params, row0=0, rows=None):
         W, H = camera.image_width, camera.image_height
         rows = H - row0 if rows is None else rows

@@ -3,6 +3,8 @@
 // built from rt_kernels.hip (embedded below with .incbin).  It takes the place of the reference's
 // cudarc-based CudaWorld (gpu-implementation/src/ray_tracing.rs:73-211).  Host C++ only.
 #include <hip/hip_runtime_api.h>
+#include <rccl/rccl.h>   // types only: the RCCL entry points are resolved at run time (dlopen), see Rccl below
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cmath>
@@ -33,7 +35,7 @@ struct rt_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipModule_t module = nullptr;
-    hipFunction_t f_render = nullptr, f_render_stream = nullptr, f_hits = nullptr, f_random = nullptr;
+    hipFunction_t f_render = nullptr, f_render_stream = nullptr, f_hits = nullptr, f_random = nullptr, f_assemble = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     void *d_geom = nullptr, *d_exact = nullptr, *d_shade = nullptr, *d_mat = nullptr;
     float translate[3] = {0.0f, 0.0f, 0.0f};
@@ -41,6 +43,11 @@ struct rt_ctx {
     bool have_scene = false;
     void *d_rgba = nullptr, *d_linear = nullptr, *d_hits = nullptr, *d_counter = nullptr;
     size_t cap_rgba = 0, cap_linear = 0, cap_hits = 0;
+    // multi-GPU gather: this context is rank `rank` of `world`
+    ncclComm_t comm = nullptr;
+    uint32_t world = 1, rank = 0;
+    void *d_tiles = nullptr, *d_frame = nullptr;     // rank's tile buffer (rank 0: all ranks' buffers), assembled frame
+    size_t cap_tiles = 0, cap_frame = 0;
     float last_ms = 0.0f;
     int compute_units = 0, clock_khz = 0;
     char name[600] = {0};
@@ -78,18 +85,19 @@ int ensure(rt_ctx* c, void** p, size_t* cap, size_t bytes) {
 int load_image(rt_ctx* c, const void* image) {
     hipModule_t m = nullptr;
     RT_HIP(c, hipModuleLoadData(&m, image));
-    hipFunction_t fr, fs, fh, fx;
+    hipFunction_t fr, fs, fh, fx, fa;
     hipError_t e;
     if ((e = hipModuleGetFunction(&fr, m, "rt_render")) != hipSuccess ||
         (e = hipModuleGetFunction(&fs, m, "rt_render_stream")) != hipSuccess ||
         (e = hipModuleGetFunction(&fh, m, "rt_primary_hits")) != hipSuccess ||
-        (e = hipModuleGetFunction(&fx, m, "rt_show_random")) != hipSuccess) {
+        (e = hipModuleGetFunction(&fx, m, "rt_show_random")) != hipSuccess ||
+        (e = hipModuleGetFunction(&fa, m, "rt_assemble")) != hipSuccess) {
         (void)hipModuleUnload(m);
         return hip_fail(c, e, "hipModuleGetFunction");
     }
     if (c->module) (void)hipModuleUnload(c->module);
     c->module = m;
-    c->f_render = fr; c->f_render_stream = fs; c->f_hits = fh; c->f_random = fx;
+    c->f_render = fr; c->f_render_stream = fs; c->f_hits = fh; c->f_random = fx; c->f_assemble = fa;
     return 0;
 }
 
@@ -226,11 +234,87 @@ int launch_hits(rt_ctx* c, const RtCamera* cam, const RtParams* p, RtLaunch L, v
     return 0;
 }
 
+// RCCL, bound at first use so that single-GPU users never load it and a process that already holds an RCCL
+// (PyTorch-ROCm ships its own) keeps using that one.  RT_RCCL_LIB names the library to load.
+struct Rccl {
+    void* handle = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    std::string error;
+};
+
+Rccl* rccl() {
+    static Rccl r;
+    if (r.handle || !r.error.empty()) return &r;
+    const char* env = std::getenv("RT_RCCL_LIB");
+    const char* names[] = {env, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* n : names) {
+        if (!n || !*n) continue;
+        r.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
+        if (!r.handle) r.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+        if (r.handle) break;
+    }
+    if (!r.handle) { r.error = std::string("cannot load RCCL: ") + (dlerror() ? dlerror() : "not found"); return &r; }
+    bool ok = true;
+    auto sym = [&](const char* name) { void* p = dlsym(r.handle, name); if (!p) { ok = false; r.error = std::string("RCCL lacks ") + name; } return p; };
+    r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
+    r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
+    r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
+    r.Send = reinterpret_cast<decltype(r.Send)>(sym("ncclSend"));
+    r.Recv = reinterpret_cast<decltype(r.Recv)>(sym("ncclRecv"));
+    r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(sym("ncclGroupStart"));
+    r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
+    r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+    if (!ok) { dlclose(r.handle); r.handle = nullptr; }
+    return &r;
+}
+
+int rccl_fail(rt_ctx* c, ncclResult_t e, const char* what) {
+    Rccl* r = rccl();
+    return fail(c, RT_ERR_COMM, std::string(what) + ": " + (r->GetErrorString ? r->GetErrorString(e) : "RCCL error"));
+}
+
+#define RT_RCCL(ctx, call)                                             \
+    do {                                                               \
+        ncclResult_t e__ = (call);                                     \
+        if (e__ != ncclSuccess) return rccl_fail((ctx), e__, #call);   \
+    } while (0)
+
+// gathered tile buffers (rank after rank, rows_per_rank rows each) -> frame in image order, on the context's stream
+int launch_assemble(rt_ctx* c, void* d_gathered, void* d_frame, uint32_t W, uint32_t H, uint32_t tile_rows,
+                    uint32_t world, uint32_t rows_per_rank) {
+    void* args[] = {&d_gathered, &d_frame, &W, &H, &tile_rows, &world, &rows_per_rank};
+    const size_t px = (size_t)W * H;
+    unsigned grid = (unsigned)std::min<size_t>((px + 255u) / 256u, (size_t)(c->compute_units > 0 ? c->compute_units : 256) * 16u);
+    RT_HIP(c, hipModuleLaunchKernel(c->f_assemble, grid, 1, 1, 256, 1, 1, 0, c->stream, args, nullptr));
+    return 0;
+}
+
+// tiles of `tile_rows` rows in an image of `height` rows owned by rank r of n: r, r+n, ...
+uint32_t tiles_of_rank(uint32_t height, uint32_t tile_rows, uint32_t r, uint32_t n) {
+    uint32_t total = (height + tile_rows - 1u) / tile_rows;
+    return r < total ? (total - r + n - 1u) / n : 0u;
+}
+
 }  // namespace
 
 extern "C" {
 
 const char* rt_last_error(const rt_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int rt_device_count(int* count) {
+    if (!count) return RT_ERR_INVALID;
+    *count = 0;
+    hipError_t e = hipGetDeviceCount(count);
+    if (e != hipSuccess) return hip_fail(nullptr, e, "hipGetDeviceCount");
+    return 0;
+}
 
 int rt_create(int device, rt_ctx** out) {
     if (!out) return RT_ERR_INVALID;
@@ -262,7 +346,8 @@ void rt_destroy(rt_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    void* bufs[] = {c->d_geom, c->d_exact, c->d_shade, c->d_mat, c->d_rgba, c->d_linear, c->d_hits, c->d_counter};
+    if (c->comm && rccl()->CommDestroy) (void)rccl()->CommDestroy(c->comm);
+    void* bufs[] = {c->d_geom, c->d_exact, c->d_shade, c->d_mat, c->d_rgba, c->d_linear, c->d_hits, c->d_counter, c->d_tiles, c->d_frame};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -434,6 +519,89 @@ int rt_device_info(const rt_ctx* c, char* name, size_t name_size, int* compute_u
     if (name && name_size) std::snprintf(name, name_size, "%s", c->name);
     if (compute_units) *compute_units = c->compute_units;
     if (clock_khz) *clock_khz = c->clock_khz;
+    return 0;
+}
+
+int rt_comm_id(uint8_t id[RT_COMM_ID_BYTES]) {
+    if (!id) return RT_ERR_INVALID;
+    Rccl* r = rccl();
+    if (!r->handle) return fail(nullptr, RT_ERR_COMM, r->error);
+    ncclUniqueId u;
+    static_assert(sizeof u == RT_COMM_ID_BYTES, "RT_COMM_ID_BYTES must be the size of ncclUniqueId");
+    RT_RCCL(nullptr, r->GetUniqueId(&u));
+    std::memcpy(id, &u, sizeof u);
+    return 0;
+}
+
+int rt_comm_init(rt_ctx* c, const uint8_t id[RT_COMM_ID_BYTES], uint32_t world, uint32_t rank) {
+    if (!c) return RT_ERR_INVALID;
+    if (!id || world == 0 || rank >= world) return fail(c, RT_ERR_INVALID, "rt_comm_init: need an id and rank < world");
+    if (c->comm) return fail(c, RT_ERR_INVALID, "rt_comm_init: this context already has a communicator");
+    Rccl* r = rccl();
+    if (!r->handle) return fail(c, RT_ERR_COMM, r->error);
+    RT_HIP(c, hipSetDevice(c->device));
+    ncclUniqueId u;
+    std::memcpy(&u, id, sizeof u);
+    RT_RCCL(c, r->CommInitRank(&c->comm, (int)world, u, (int)rank));
+    c->world = world;
+    c->rank = rank;
+    return 0;
+}
+
+int rt_assemble_tiles(rt_ctx* c, const void* d_gathered, uint32_t width, uint32_t height, uint32_t tile_rows,
+                      uint32_t world, void* d_frame) {
+    if (!c) return RT_ERR_INVALID;
+    if (!c->module) return fail(c, RT_ERR_NO_MODULE, "no code object loaded");
+    if (!d_gathered || !d_frame || !width || !height || !world || tile_rows == 0 || tile_rows % 8u != 0 ||
+        (uint64_t)width * height >= (1ull << 31))
+        return fail(c, RT_ERR_INVALID, "rt_assemble_tiles: NULL buffer, empty frame, or tile_rows not a positive multiple of 8");
+    RT_HIP(c, hipSetDevice(c->device));
+    const uint32_t rows_per_rank = tiles_of_rank(height, tile_rows, 0, world) * tile_rows;
+    int rc = launch_assemble(c, const_cast<void*>(d_gathered), d_frame, width, height, tile_rows, world, rows_per_rank);
+    if (rc) return rc;
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int rt_render_frame_sharded(rt_ctx* c, const RtCamera* cam, const RtParams* p, uint32_t tile_rows,
+                            uint8_t* frame_out, uint64_t* rays_out) {
+    int rc = check_common(c, cam, p);
+    if (rc) return rc;
+    if ((rc = check_render(c, p))) return rc;
+    if (tile_rows == 0 || tile_rows % 8u != 0) return fail(c, RT_ERR_INVALID, "tile_rows must be a positive multiple of 8");
+    if (c->rank == 0 && !frame_out) return fail(c, RT_ERR_INVALID, "frame_out is NULL on rank 0");
+    if (c->world > 1 && !c->comm) return fail(c, RT_ERR_INVALID, "rt_comm_init has not been called");
+    RT_HIP(c, hipSetDevice(c->device));
+    const uint32_t W = cam->image_width, H = cam->image_height, world = c->world, rank = c->rank;
+    const uint32_t rows_per_rank = tiles_of_rank(H, tile_rows, 0, world) * tile_rows;   // rank 0 owns the most tiles
+    const size_t part = (size_t)rows_per_rank * W * 4;                                  // bytes every rank contributes
+    // rank 0 keeps all ranks' buffers side by side and renders into the first; the others hold their own only
+    if ((rc = ensure(c, &c->d_tiles, &c->cap_tiles, rank == 0 ? part * world : part))) return rc;
+    const uint32_t mine = tiles_of_rank(H, tile_rows, rank, world);
+    uint64_t rays = 0;
+    if (mine) {
+        RtLaunch L = make_launch(c, cam, p, rank * tile_rows, mine * tile_rows, tile_rows, world * tile_rows);
+        if ((rc = launch_render(c, cam, p, L, c->d_tiles, nullptr, &rays))) return rc;
+    }
+    if (rays_out) *rays_out = rays;
+    if (world > 1) {
+        Rccl* r = rccl();
+        RT_RCCL(c, r->GroupStart());
+        if (rank == 0) {
+            for (uint32_t peer = 1; peer < world; peer++)
+                RT_RCCL(c, r->Recv(static_cast<char*>(c->d_tiles) + part * peer, part, ncclUint8, (int)peer, c->comm, c->stream));
+        } else {
+            RT_RCCL(c, r->Send(c->d_tiles, part, ncclUint8, 0, c->comm, c->stream));
+        }
+        RT_RCCL(c, r->GroupEnd());
+    }
+    if (rank == 0) {
+        const size_t frame_bytes = (size_t)W * H * 4;
+        if ((rc = ensure(c, &c->d_frame, &c->cap_frame, frame_bytes))) return rc;
+        if ((rc = launch_assemble(c, c->d_tiles, c->d_frame, W, H, tile_rows, world, rows_per_rank))) return rc;
+        RT_HIP(c, hipMemcpyAsync(frame_out, c->d_frame, frame_bytes, hipMemcpyDeviceToHost, c->stream));
+    }
+    RT_HIP(c, hipStreamSynchronize(c->stream));
     return 0;
 }
 

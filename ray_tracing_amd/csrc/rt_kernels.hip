@@ -770,3 +770,19 @@ rt_show_random(uint32_t* rgba, uint32_t n_pixels, uint32_t seed_lo, uint32_t see
     }
     rgba[p] = q[0] | (q[1] << 8) | (q[2] << 16) | (255u << 24);
 }
+
+// ---------------------------------------------------------------- multi-GPU frame assembly
+// `gathered` holds, rank after rank, each rank's compact buffer of interleaved row tiles (rank r owns tiles
+// r, r + world, ...; rows_per_rank rows each, padded to the largest rank); writes the frame in image order.
+// One RGBA8 pixel per work-item, grid-stride.
+extern "C" __global__ void __launch_bounds__(256)
+rt_assemble(const uint32_t* __restrict__ gathered, uint32_t* __restrict__ frame, uint32_t width, uint32_t height,
+            uint32_t tile_rows, uint32_t world, uint32_t rows_per_rank) {
+    const size_t n = (size_t)width * height;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t y = (uint32_t)(idx / width), x = (uint32_t)(idx - (size_t)y * width);
+        const uint32_t t = y / tile_rows, r = t % world, k = t / world;
+        const uint32_t local_row = k * tile_rows + (y - t * tile_rows);
+        frame[idx] = gathered[((size_t)r * rows_per_rank + local_row) * width + x];
+    }
+}

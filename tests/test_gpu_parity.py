@@ -319,6 +319,54 @@ def test_interleaved_tiles_into_device_memory(rt, hip):
         assert rays == full["rays"]
 
 
+def test_assemble_kernel_puts_gathered_tiles_in_image_order(rt, hip):
+    """rt_assemble_tiles: the copy kernel behind the multi-GPU gather.  The tile buffers of 1, 2, 3 and 5 ranks,
+    laid out back to back as a gather leaves them on rank 0, come out as the single-launch frame."""
+    torch = pytest.importorskip("torch")
+    from ray_tracing_amd import tiles
+    sp = rt.scene_book1_final(1)
+    cam = rt.Camera.look_at(16.0 / 9.0, 136, 20.0, (13.0, 2.0, 3.0), (0.0, 0.0, 0.0))   # H = 76: last tile ragged
+    p = rt.DeviceGUI(samples_per_pixel=3, max_depth=10, seed=4, sample_chunk=1)
+    hip.upload_scene(sp)
+    full = hip.render(cam, p)
+    W, H, TR = cam.image_width, cam.image_height, 8
+    for world in (1, 2, 3, 5):
+        per_rank = tiles.max_tiles_per_rank(H, world) * TR
+        gathered = torch.full((world, per_rank, W, 4), 77, dtype=torch.uint8, device="cuda")
+        for rank in range(world):
+            n = len(tiles.tiles_of_rank(H, rank, world))
+            hip.render_tiles_device(cam, p, TR, rank, world, n, gathered[rank].data_ptr())
+        frame = torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        hip.assemble_tiles(gathered.data_ptr(), W, H, TR, world, frame.data_ptr())
+        assert np.array_equal(frame.cpu().numpy(), full["rgba"])
+        assert np.array_equal(tiles.assemble([gathered[r].cpu() for r in range(world)], H).numpy(), full["rgba"])
+
+
+def test_sharded_frame_entry_point_single_rank(rt):
+    """rt_render_frame_sharded as rank 0 of 1, without and with an RCCL communicator (rt_comm_id /
+    rt_comm_init load RCCL and create a one-rank communicator on this GPU): the frame is the one
+    rt_render_rows returns.  More ranks need more GPUs than this test has; their tile arithmetic is covered
+    by the assemble test above and the row mapping by the tile tests."""
+    sp = rt.scene_book1_final(1)
+    cam = rt.Camera.look_at(16.0 / 9.0, 200, 20.0, (13.0, 2.0, 3.0), (0.0, 0.0, 0.0))      # H = 112
+    p = rt.DeviceGUI(samples_per_pixel=6, max_depth=20, seed=12, sample_chunk=2)
+    w = rt.HipWorld(0, sp)
+    try:
+        ref = w.render(cam, p)
+        got = w.render_frame_sharded(cam, p, tile_rows=16)
+        assert np.array_equal(got["rgba"], ref["rgba"]) and got["rays"] == ref["rays"]
+        w.comm_init(rt.HipWorld.comm_id(), 1, 0)
+        got = w.render_frame_sharded(cam, p, tile_rows=8)
+        assert np.array_equal(got["rgba"], ref["rgba"]) and got["rays"] == ref["rays"]
+        with pytest.raises(rt.RtError):
+            w.comm_init(rt.HipWorld.comm_id(), 1, 0)          # one communicator per context
+        with pytest.raises(rt.RtError):
+            w.render_frame_sharded(cam, p, tile_rows=12)      # tile_rows must be a multiple of 8
+    finally:
+        w.close()
+
+
 def test_show_random_views(oracle, rt, hip):
     for norm in (False, True):
         got = hip.show_random(100, 37, seed=5, norm=norm)

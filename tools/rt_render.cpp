@@ -1,13 +1,17 @@
-// rt_render -- command-line front end: renders one of the built-in scenes on GPU 0 and writes a PPM.
+// rt_render -- command-line front end: renders one of the built-in scenes on one or more GPUs and writes a PPM.
 // It is the headless counterpart of the reference's two window apps (cpu-implementation/src/main.rs,
 // gpu-implementation/src/main.rs): same scenes, cameras and defaults, no window.
 //   rt_render --scene cpu|gpu|book1|grid|hall [--width W] [--spp N | --grid n] [--depth D] [--seed S]
-//             [--chunk C] [--out image.ppm] [--p3f linear.ppm]
+//             [--chunk C] [--out image.ppm] [--p3f linear.ppm] [--gpus N] [--frames K]
+// --gpus N (> 1): one host thread and one context per GPU; the frame is dealt out as interleaved 8-row tiles and
+// gathered to GPU 0 with RCCL (rt_render_frame_sharded).  --frames K renders the frame K times and reports the last.
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
+#include <thread>
 
 #include "../include/rt_host.hpp"
 
@@ -27,6 +31,9 @@ int main(int argc, char** argv) {
         uint32_t chunk = (uint32_t)std::atoi(arg(argc, argv, "--chunk", "0"));
         std::string out = arg(argc, argv, "--out", "image.ppm");
         std::string p3f = arg(argc, argv, "--p3f", "");
+        uint32_t gpus = (uint32_t)std::atoi(arg(argc, argv, "--gpus", "1"));
+        uint32_t frames = (uint32_t)std::atoi(arg(argc, argv, "--frames", "1"));
+        if (gpus == 0 || frames == 0) { std::fprintf(stderr, "--gpus and --frames must be >= 1\n"); return 2; }
 
         rt::World world;
         rt::Camera cam;
@@ -46,12 +53,56 @@ int main(int argc, char** argv) {
         }
         p.sample_chunk = chunk;
 
-        rt::HipWorld hip(0, world);
         std::vector<uint8_t> frame((size_t)cam.image_width() * cam.image_height() * 4);
+        if (gpus > 1) {
+            if (!p3f.empty()) { std::fprintf(stderr, "--p3f needs --gpus 1\n"); return 2; }
+            int have = 0;
+            if (rt_device_count(&have) != 0 || (uint32_t)have < gpus) {      // a missing rank would leave the others waiting in RCCL
+                std::fprintf(stderr, "rt_render: --gpus %u but %d GPU(s) are visible\n", gpus, have);
+                return 2;
+            }
+            const std::vector<uint8_t> id = rt::HipWorld::comm_id();
+            std::vector<uint64_t> rays(gpus, 0);
+            std::vector<float> kernel_ms(gpus, 0.0f);
+            std::vector<std::string> errors(gpus);
+            std::vector<double> wall(gpus, 0.0);
+            std::vector<std::thread> ranks;
+            for (uint32_t r = 0; r < gpus; r++)
+                ranks.emplace_back([&, r] {
+                    try {
+                        rt::HipWorld hip((int)r, world);
+                        hip.comm_init(id, gpus, r);
+                        for (uint32_t f = 0; f < frames; f++) {
+                            auto t0 = std::chrono::steady_clock::now();
+                            rays[r] = hip.render_sharded(r == 0 ? frame.data() : nullptr, cam, p);
+                            wall[r] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                        }
+                        kernel_ms[r] = hip.last_kernel_ms();
+                    } catch (const std::exception& e) { errors[r] = e.what(); }
+                });
+            for (auto& t : ranks) t.join();
+            uint64_t total = 0;
+            float slowest = 0.0f;
+            for (uint32_t r = 0; r < gpus; r++) {
+                if (!errors[r].empty()) throw std::runtime_error("GPU " + std::to_string(r) + ": " + errors[r]);
+                total += rays[r];
+                if (kernel_ms[r] > slowest) slowest = kernel_ms[r];
+            }
+            std::printf("Calculation took %.3f ms on %u GPUs (slowest kernel %.3f ms): %ux%u, %zu spheres, %u spp, depth %u, %llu ray segments, %.1f Mrays/s\n",
+                        wall[0] * 1e3, gpus, slowest, cam.image_width(), cam.image_height(), world.size(), p.samples_per_pixel,
+                        p.max_depth, (unsigned long long)total, total / (wall[0] * 1e6));
+            rt::write_ppm(out, frame, cam.image_width(), cam.image_height());
+            return 0;
+        }
+        rt::HipWorld hip(0, world);
         std::vector<float> linear(p3f.empty() ? 0 : frame.size());
-        auto t0 = std::chrono::steady_clock::now();
-        uint64_t rays = hip.render(frame.data(), cam, p, linear.empty() ? nullptr : linear.data());
-        double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        uint64_t rays = 0;
+        double wall = 0.0;
+        for (uint32_t f = 0; f < frames; f++) {
+            auto t0 = std::chrono::steady_clock::now();
+            rays = hip.render(frame.data(), cam, p, linear.empty() ? nullptr : linear.data());
+            wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        }
         std::printf("Calculation took %.3f ms (kernel %.3f ms): %ux%u, %zu spheres, %u spp, depth %u, %llu ray segments, %.1f Mrays/s\n",
                     wall * 1e3, hip.last_kernel_ms(), cam.image_width(), cam.image_height(), world.size(), p.samples_per_pixel,
                     p.max_depth, (unsigned long long)rays, rays / (hip.last_kernel_ms() * 1e3));   // cpu main.rs:62-64 prints the time
