@@ -535,7 +535,7 @@ RT_DEV void render_body(const Scene& sc, uint32_t* __restrict__ rgba, float4* __
     uint32_t cur = 1u;                                           // slot items are handed out from
     uint32_t next = n_items;                                     // its next unclaimed item; n_items: none left (or none open yet)
     bool drained = false;                                        // the launch's unit counter has run out
-    bool need = true, active = false;
+    bool need = true, active = false, new_path = false;
     uint32_t seg = 0u, nb = 0u, nseg = 0u;
     V3 run = v3(0.0f, 0.0f, 0.0f), thr = v3(1.0f, 1.0f, 1.0f);
     V3 o = v3(0.0f, 0.0f, 0.0f), d = v3(0.0f, 0.0f, 1.0f);
@@ -584,8 +584,8 @@ RT_DEV void render_body(const Scene& sc, uint32_t* __restrict__ rgba, float4* __
                         if (it.x < L.width && ly < L.rows_local && it.y < L.height && it.s < it.s_end) {
                             need = false;
                             active = true;
+                            new_path = true;
                             run = v3(0.0f, 0.0f, 0.0f);
-                            sample_ray(cam, L, seed, it.x, it.y, it.pixel, it.s, o, d);
                         } else {
                             skipped = true;                      // pixel outside the image: nothing to trace
                         }
@@ -597,6 +597,11 @@ RT_DEV void render_body(const Scene& sc, uint32_t* __restrict__ rgba, float4* __
                 const uint32_t n_skipped = (uint32_t)__popcll(__ballot(skipped));
                 if (cur) u1.left -= n_skipped; else u0.left -= n_skipped;
             }
+        }
+        // one place generates camera rays: for the first sample of a new item and for the next sample of a running one
+        if (new_path) {
+            sample_ray(cam, L, seed, it.x, it.y, it.pixel, it.s, o, d);
+            new_path = false;
         }
         st.lap(14);
         const bool more = active || !drained || next < n_items || u0.open || u1.open;
@@ -661,7 +666,7 @@ RT_DEV void render_body(const Scene& sc, uint32_t* __restrict__ rgba, float4* __
                 nb = 0u;
                 thr = v3(1.0f, 1.0f, 1.0f);
                 if (it.s < it.s_end) {
-                    sample_ray(cam, L, seed, it.x, it.y, it.pixel, it.s, o, d);
+                    new_path = true;                             // camera ray at the top of the next trip
                 } else {                                         // run complete: hand its sum to the pixel
                     if (exact_sum) {
                         atomicAdd(accum + it.pix, (unsigned long long)to_fixed(run.x));
