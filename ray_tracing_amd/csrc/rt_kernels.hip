@@ -300,7 +300,9 @@ RT_DEV V3 scatter(uint32_t mat, float param, V3 d, const HitInfo& h, Rng& g, uin
         asm volatile("" :: "v"(r2.x), "v"(r2.y), "v"(r2.z));
     }
 #endif
-    V3 ru = random_unit_vector(g, st);
+    // glass never looks at the random vector, and the stream ends with this segment: its lanes skip the loop
+    V3 ru = v3(0.0f, 0.0f, 0.0f);
+    if ((flags & RT_FLAG_BAND_ALBEDO) || mat != RT_MAT_DIELECTRIC) ru = random_unit_vector(g, st);
     V3 n = h.n;
     V3 out;
     if ((flags & RT_FLAG_BAND_ALBEDO) || mat == RT_MAT_DIFFUSE) {
