@@ -44,14 +44,8 @@ typedef struct RtLaunch {
 #define RT_TILE_SPHERES 1024u
 // Candidate slots per lane (u16 each, in LDS); a wavefront drains its lists as soon as one lane's list
 // is full (checked after every push, so a list can never overflow).
-#ifdef RT_BALANCED_DRAIN
-#define RT_CAND_CAP 384u
-#define RT_CAND_LDS_PER_WAVE (RT_CAND_CAP * 2u + 64u * 8u)
-#else
 #ifndef RT_CAND_CAP
 #define RT_CAND_CAP 16u
-#endif
-#define RT_CAND_LDS_PER_WAVE (RT_CAND_CAP * 64u * 2u)
 #endif
 
 #endif

@@ -190,7 +190,7 @@ void launch_geometry(const RtParams* p, uint32_t n_wave_units, unsigned* grid, u
 // candidate-list block and the pixel accumulators of its two open units.
 size_t lds_bytes(const rt_ctx* c, unsigned block, unsigned unit_pixels) {
     uint32_t n = c->n_padded < RT_TILE_SPHERES ? c->n_padded : RT_TILE_SPHERES;
-    return (size_t)n * 32u + (size_t)(block / 64u) * (RT_CAND_LDS_PER_WAVE + 2u * 3u * unit_pixels * 8u);
+    return (size_t)n * 32u + (size_t)(block / 64u) * (RT_CAND_CAP * 64u * 2u + 2u * 3u * unit_pixels * 8u);
 }
 
 // One render launch into device buffers; blocking; fills last_ms and (optionally) the segment count.

@@ -138,52 +138,6 @@ struct Tile { const float4* geo; const float4* exa; };
 
 // Per-lane list of candidate spheres of the tile being scanned, kept in LDS as a column of a
 // [RT_CAND_CAP][64] u16 array per wavefront (lane l owns column l, so pushes never conflict).
-#ifdef RT_BALANCED_DRAIN
-struct Cand { uint16_t* list; unsigned long long* best; uint32_t count; };
-RT_DEV float lane_read(int byte_addr, float v) { return __int_as_float(__builtin_amdgcn_ds_bpermute(byte_addr, __float_as_int(v))); }
-RT_DEV bool root_exact(float h, float ncc, float disc, float a, float t_min, float t_max, float& root) {
-    bool ok = false;
-    if (disc >= 0.0f && (h > 0.0f || ncc > 0.0f)) {
-        float s = sqrtf(disc);
-        float root_a = (h - s) / a;
-        float root_b = (h + s) / a;
-        root = root_a;
-        ok = (t_min < root_a) && (root_a < t_max);
-        if (!ok) { root = root_b; ok = (t_min < root_b) && (root_b < t_max); }
-    }
-    return ok;
-}
-RT_DEV void drain(const Tile& tile, int base, Cand& c, V3 o, V3 d, float a, float t_min, float t_max, Best& b, Stats& st) {
-    st.wave(6);
-    const uint32_t lane = threadIdx.x & 63u;
-    const unsigned long long act = __ballot(1);
-    const uint32_t n_act = (uint32_t)__popcll(act);
-    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(act >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)act, 0u));
-    c.best[lane] = ((unsigned long long)__float_as_uint(b.t) << 32) | (unsigned long long)(uint32_t)b.idx;
-    for (uint32_t first = 0u; first < c.count; first += n_act) {
-        st.wave(3);
-        const uint32_t j = first + rank;
-        const bool valid = j < c.count;
-        const uint32_t e = valid ? (uint32_t)c.list[j] : 0u;
-        const uint32_t src = e >> 10, i = e & 1023u;
-        const int at = (int)(src << 2);
-        const V3 so = v3(lane_read(at, o.x), lane_read(at, o.y), lane_read(at, o.z));
-        const V3 sd = v3(lane_read(at, d.x), lane_read(at, d.y), lane_read(at, d.z));
-        const float sa = lane_read(at, a);
-        if (valid) {
-            const float4 g = tile.exa[i];
-            float h, ncc, disc, root;
-            sphere_terms(g.x, g.y, g.z, g.w, so, sd, sa, h, ncc, disc);
-            if (root_exact(h, ncc, disc, sa, t_min, t_max, root))
-                atomicMin(c.best + src, ((unsigned long long)__float_as_uint(root) << 32) | (unsigned long long)(uint32_t)(base + (int)i));
-        }
-    }
-    const unsigned long long w = __hip_atomic_load(c.best + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-    b.t = __uint_as_float((uint32_t)(w >> 32));
-    b.idx = (int)(uint32_t)w;
-    c.count = 0u;
-}
-#else
 struct Cand { uint16_t* col; uint32_t n; };
 
 RT_DEV void push(Cand& c, uint32_t idx) {
@@ -210,7 +164,6 @@ RT_DEV void drain(const Tile& tile, int base, Cand& c, V3 o, V3 d, float a, floa
     }
     c.n = 0u;
 }
-#endif
 
 // Scan `count` (a multiple of RT_SCAN_UNROLL) spheres staged in LDS; every lane of the wavefront reads
 // the same float4 per sphere.  The scan only has to list, per lane, a SUPERSET of the spheres the exact
@@ -243,8 +196,7 @@ RT_DEV void drain(const Tile& tile, int base, Cand& c, V3 o, V3 d, float a, floa
 // (Reading the filter data with scalar loads instead -- wave-uniform global addresses, the four values of a
 // sphere as SGPR operands -- was built and measured 19 % slower than the LDS tile on the 485-sphere scene.)
 RT_DEV void scan_tile(const Tile& tile, uint32_t count, int base, V3 T,
-                      V3 o, V3 d, float a, float t_min, float t_max, Best& b, Cand& c, Stats& st) {
-    (void)t_max;
+                      V3 o, V3 d, float a, float t_min, Best& b, Cand& c, Stats& st) {
     st.wave(1);
     const V3 op = vsub(o, T);
     const float inv_len = (1.0f / sqrtf(a)) * (1.0f + 0x1p-19f);
@@ -285,26 +237,6 @@ RT_DEV void scan_tile(const Tile& tile, uint32_t count, int base, V3 T,
             c.n = n0;
         }
 #endif
-#ifdef RT_BALANCED_DRAIN
-        unsigned long long any;
-        while ((any = __ballot(bits != 0u)) != 0ull) {
-            st.wave(4);
-            if (bits != 0u) {
-                st.add(2, 1u);
-                const uint32_t pos = 31u - (uint32_t)__clz((int)bits);
-                const uint32_t slot = c.count + __builtin_amdgcn_mbcnt_hi((uint32_t)(any >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)any, 0u));
-                c.list[slot] = (uint16_t)(((threadIdx.x & 63u) << 10) | (blk + (k - 1u - pos)));
-                bits &= ~(1u << pos);
-            }
-            c.count += (uint32_t)__popcll(any);
-            if (c.count > RT_CAND_CAP - 64u) { st.lap(10); drain(tile, base, c, o, d, a, t_min, t_max, b, st); st.lap(11); }
-        }
-        st.lap(10);
-    }
-    drain(tile, base, c, o, d, a, t_min, t_max, b, st);
-    st.lap(11);
-}
-#else
         while (__ballot(bits != 0u) != 0ull) {
             st.wave(4);
             if (bits != 0u) {
@@ -320,7 +252,6 @@ RT_DEV void scan_tile(const Tile& tile, uint32_t count, int base, V3 T,
     drain(tile, base, c, o, d, a, t_min, b, st);
     st.lap(11);
 }
-#endif
 
 // ---------------------------------------------------------------- shading
 struct Scene {
@@ -478,21 +409,6 @@ RT_DEV Tile stage_tile(const RtLaunch& L, const float4* __restrict__ geom, const
     return t;
 }
 
-#ifdef RT_BALANCED_DRAIN
-#define RT_CAND_BYTES (RT_CAND_CAP * 2u + 64u * 8u)
-RT_DEV unsigned long long* accum_base(const RtLaunch& L) {
-    char* cand = reinterpret_cast<char*>(rt_lds + 2u * tile_capacity(L));
-    return reinterpret_cast<unsigned long long*>(cand + (blockDim.x >> 6) * RT_CAND_BYTES);
-}
-RT_DEV Cand cand_list(const RtLaunch& L) {
-    char* mine = reinterpret_cast<char*>(rt_lds + 2u * tile_capacity(L)) + (threadIdx.x >> 6) * RT_CAND_BYTES;
-    Cand c;
-    c.best = reinterpret_cast<unsigned long long*>(mine);
-    c.list = reinterpret_cast<uint16_t*>(mine + 64u * 8u);
-    c.count = 0u;
-    return c;
-}
-#else
 RT_DEV unsigned long long* accum_base(const RtLaunch& L) {
     uint16_t* cand = reinterpret_cast<uint16_t*>(rt_lds + 2u * tile_capacity(L));
     return reinterpret_cast<unsigned long long*>(cand + (blockDim.x >> 6) * (RT_CAND_CAP * 64u));
@@ -505,7 +421,6 @@ RT_DEV Cand cand_list(const RtLaunch& L) {
     c.n = 0u;
     return c;
 }
-#endif
 
 // ---------------------------------------------------------------- render
 // Run sum -> 2^-32 fixed point (floor part + truncated fraction); values that are not finite and below
@@ -708,10 +623,10 @@ RT_DEV void render_body(const Scene& sc, uint32_t* __restrict__ rgba, float4* __
                 if (first) __syncthreads();                      // previous tile fully scanned
                 tile = stage_tile(L, sc.geom, sc.exact, first, count);
                 __syncthreads();
-                if (active) scan_tile(tile, count, (int)first, T, o, d, a, L.t_min, L.t_max, b, cand, st);
+                if (active) scan_tile(tile, count, (int)first, T, o, d, a, L.t_min, b, cand, st);
             }
         } else {
-            if (active) scan_tile(tile, L.n_padded, 0, T, o, d, a, L.t_min, L.t_max, b, cand, st);
+            if (active) scan_tile(tile, L.n_padded, 0, T, o, d, a, L.t_min, b, cand, st);
         }
         bool finished = false;                                   // this lane completed its item in this round
         if (active) {
@@ -832,7 +747,7 @@ rt_primary_hits(const float4* geom, const float4* exact, int32_t* hits, RtCamera
         if (first) __syncthreads();
         Tile tile = stage_tile(L, geom, exact, first, count);
         __syncthreads();
-        if (valid) scan_tile(tile, count, (int)first, ld3(L.translate), o, d, a, L.t_min, L.t_max, b, cand, st);
+        if (valid) scan_tile(tile, count, (int)first, ld3(L.translate), o, d, a, L.t_min, b, cand, st);
     }
     if (valid) hits[(size_t)ly * L.width + x] = b.idx;
 }
