@@ -60,7 +60,7 @@ if pmc.get("GRBM_GUI_ACTIVE"):
     k_s = sum(durs) / len(durs) * 1e-3
     clk = pmc["GRBM_GUI_ACTIVE"] / 8 / k_s
     w(f"  effective shader clock             {clk / 1e9:.2f} GHz (GRBM_GUI_ACTIVE / 8 XCDs / kernel time)")
-    w(f"  VALU wave-instructions per SIMD per cycle  {pmc['SQ_INSTS_VALU'] / 1024 / (pmc['GRBM_GUI_ACTIVE'] / 8):.3f} (tools/microbench/valu_rate measures 0.39 for a pure v_fma_f32 stream at 8 waves per SIMD)")
+    w(f"  VALU wave-instructions per SIMD per cycle  {pmc['SQ_INSTS_VALU'] / 1024 / (pmc['GRBM_GUI_ACTIVE'] / 8):.3f} (tools/microbench/vgpr_bank: a pure v_fma_f32 stream issues 0.42 at 8 waves per SIMD, 0.36 at 4)")
     w(f"  resident waves per SIMD (SQ_WAVE_CYCLES*4 / cycles / 1024)  {pmc['SQ_WAVE_CYCLES'] * 4 / (pmc['GRBM_GUI_ACTIVE'] / 8) / 1024:.2f}" if pmc.get("SQ_WAVE_CYCLES") else "")
 hbm = None
 if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
