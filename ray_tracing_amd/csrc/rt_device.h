@@ -47,5 +47,8 @@ typedef struct RtLaunch {
 #ifndef RT_CAND_CAP
 #define RT_CAND_CAP 16u
 #endif
+// Kernel for sample_chunk = 1 (camera rays in batches): candidate slots per lane, 32-bit words per queued ray
+#define RT_Q_CAND_CAP 8u
+#define RT_Q_WORDS 8u
 
 #endif

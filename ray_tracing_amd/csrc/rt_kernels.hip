@@ -138,7 +138,7 @@ struct Tile { const float4* geo; const float4* exa; };
 
 // Per-lane list of candidate spheres of the tile being scanned, kept in LDS as a column of a
 // [RT_CAND_CAP][64] u16 array per wavefront (lane l owns column l, so pushes never conflict).
-struct Cand { uint16_t* col; uint32_t n; };
+struct Cand { uint16_t* col; uint32_t n; uint32_t cap; };   // cap: slots per lane (wave-uniform)
 
 RT_DEV void push(Cand& c, uint32_t idx) {
     c.col[c.n * 64u] = (uint16_t)idx;
@@ -163,6 +163,39 @@ RT_DEV void drain(const Tile& tile, int base, Cand& c, V3 o, V3 d, float a, floa
         }
     }
     c.n = 0u;
+}
+
+// The clear bits of one block's mask (bit j: sphere blk + (k-1-j)) become entries of the lanes' candidate
+// lists, lowest sphere index first; full lists are drained on the spot.
+RT_DEV void decode_block(const Tile& tile, int base, uint32_t blk, uint32_t k, uint32_t miss,
+                         V3 o, V3 d, float a, float t_min, Best& b, Cand& c, Stats& st) {
+    uint32_t bits = ~miss & (k == 32u ? 0xffffffffu : ((1u << k) - 1u));
+#ifdef RT_EXP_DECODE2
+    {   // cost experiment: the decode loop once more into the same slots, then forgotten
+        uint32_t bits2 = bits;
+        const uint32_t n0 = c.n;
+        while (__ballot(bits2 != 0u) != 0ull) {
+            if (bits2 != 0u) {
+                uint32_t pos = 31u - (uint32_t)__clz((int)bits2);
+                push(c, blk + (k - 1u - pos));
+                bits2 &= ~(1u << pos);
+            }
+            if (__ballot(c.n >= c.cap) != 0ull) c.n = n0;
+        }
+        c.n = n0;
+    }
+#endif
+    while (__ballot(bits != 0u) != 0ull) {
+        st.wave(4);
+        if (bits != 0u) {
+            st.add(2, 1u);
+            uint32_t pos = 31u - (uint32_t)__clz((int)bits);        // highest bit = lowest sphere index first
+            push(c, blk + (k - 1u - pos));
+            bits &= ~(1u << pos);
+        }
+        if (__ballot(c.n >= c.cap) != 0ull) { st.lap(10); drain(tile, base, c, o, d, a, t_min, b, st); st.lap(11); }
+    }
+    st.lap(10);
 }
 
 // Scan `count` (a multiple of RT_SCAN_UNROLL) spheres staged in LDS; every lane of the wavefront reads
@@ -221,36 +254,42 @@ RT_DEV void scan_tile(const Tile& tile, uint32_t count, int base, V3 T,
             }
         }
         st.lap(9);
-        uint32_t bits = ~miss & (k == 32u ? 0xffffffffu : ((1u << k) - 1u));
-#ifdef RT_EXP_DECODE2
-        {   // cost experiment: the decode loop once more into the same slots, then forgotten
-            uint32_t bits2 = bits;
-            const uint32_t n0 = c.n;
-            while (__ballot(bits2 != 0u) != 0ull) {
-                if (bits2 != 0u) {
-                    uint32_t pos = 31u - (uint32_t)__clz((int)bits2);
-                    push(c, blk + (k - 1u - pos));
-                    bits2 &= ~(1u << pos);
-                }
-                if (__ballot(c.n >= RT_CAND_CAP) != 0ull) c.n = n0;
-            }
-            c.n = n0;
-        }
-#endif
-        while (__ballot(bits != 0u) != 0ull) {
-            st.wave(4);
-            if (bits != 0u) {
-                st.add(2, 1u);
-                uint32_t pos = 31u - (uint32_t)__clz((int)bits);        // highest bit = lowest sphere index first
-                push(c, blk + (k - 1u - pos));
-                bits &= ~(1u << pos);
-            }
-            if (__ballot(c.n >= RT_CAND_CAP) != 0ull) { st.lap(10); drain(tile, base, c, o, d, a, t_min, b, st); st.lap(11); }
-        }
-        st.lap(10);
+        decode_block(tile, base, blk, k, miss, o, d, a, t_min, b, c, st);
     }
     drain(tile, base, c, o, d, a, t_min, b, st);
     st.lap(11);
+}
+
+// The scan for camera rays.  They all leave from the camera centre, so the origin-dependent half of the
+// filter, t + m = k0 + w.c' + m, is one number per sphere for the whole launch (computed when the tile is staged,
+// with the operations of scan_tile, and kept as the fourth word of a second copy of the filter data: one
+// 16-byte LDS read per sphere, as in scan_tile) and the scan is g (3 fma), key = fma(g, g, t + m) (1) and the sign
+// bit (1): 5 operations per sphere and lane instead of 9.  One rounding moves from the end of the chain to
+// that number; the bound of scan_tile's derivation and its slack are unchanged.
+RT_DEV void scan_primary(const float4* __restrict__ geo0, const Tile& tile, uint32_t count, V3 T,
+                         V3 o, V3 d, float a, float t_min, Best& b, Cand& c, Stats& st) {
+    st.wave(0);
+    const V3 op = vsub(o, T);
+    const float inv_len = (1.0f / sqrtf(a)) * (1.0f + 0x1p-19f);
+    const V3 uf = v3(d.x * inv_len, d.y * inv_len, d.z * inv_len);
+    const float e = -vdot(uf, op);
+    for (uint32_t blk = 0; blk < count; blk += 32u) {
+        const uint32_t k = (count - blk) < 32u ? (count - blk) : 32u;
+        uint32_t miss = 0u;
+        for (uint32_t i = 0; i < k; i += RT_SCAN_UNROLL) {
+            float4 s[RT_SCAN_UNROLL];
+#pragma unroll
+            for (uint32_t u = 0; u < RT_SCAN_UNROLL; u++) s[u] = geo0[blk + i + u];
+#pragma unroll
+            for (uint32_t u = 0; u < RT_SCAN_UNROLL; u++) {
+                const float g = fmaf(uf.z, s[u].z, fmaf(uf.y, s[u].y, fmaf(uf.x, s[u].x, e)));
+                const float key = fmaf(g, g, s[u].w);
+                miss = __builtin_amdgcn_alignbit(miss, __float_as_uint(key), 31u);
+            }
+        }
+        decode_block(tile, 0, blk, k, miss, o, d, a, t_min, b, c, st);
+    }
+    drain(tile, 0, c, o, d, a, t_min, b, st);
 }
 
 // ---------------------------------------------------------------- shading
@@ -419,6 +458,7 @@ RT_DEV Cand cand_list(const RtLaunch& L) {
     Cand c;
     c.col = base + (threadIdx.x >> 6) * (RT_CAND_CAP * 64u) + (threadIdx.x & 63u);
     c.n = 0u;
+    c.cap = RT_CAND_CAP;
     return c;
 }
 
@@ -711,11 +751,284 @@ RT_DEV void render_body(const Scene& sc, uint32_t* __restrict__ rgba, float4* __
     }
 }
 
+// ---------------------------------------------------------------- render, camera rays traced in batches
+// Used when every sample is its own work item (sample_chunk = 1) and the sphere list fits the LDS tile.
+// A third of all path segments are camera rays, and those share their origin: the wavefront traces them 64
+// at a time with scan_primary (5 operations per sphere instead of 9, every lane busy), shades them on the
+// spot -- a miss is a finished sample and goes straight to the pixel's accumulator -- and queues the
+// scattered rays of the hits in LDS.  The loop of render_body then runs on bounce segments only: a lane
+// whose path has ended takes the next queued ray; when the queue is empty the next batch of camera rays
+// of the unit is traced.  Image and segment count are those of render_body with sample_chunk = 1, bit for bit.
+//   LDS: [geo S float4][exa S float4][geo0 S float4] then per wavefront
+//        [candidate lists RT_Q_CAND_CAP x 64 u16][accumulators 2 x 3 x P u64][queue RT_Q_WORDS x 64 u32]
+// RT_Q_WORDS (rt_device.h) = 8 words per queued ray: origin xyz, direction xyz, sample,
+// (slot * 64 + pixel of unit) << 16 | sphere hit
+
+struct Path { V3 o, d, thr; uint32_t seg, nb; };
+
+// Shades the segment that ended in `b`: scatter at the hit (ray.cu:35-40) or sky colour (ray.cu:43-45,
+// lib.rs:195-205).  Returns true when the path is over, with its colour.
+RT_DEV bool shade_segment(const Scene& sc, const RtLaunch& L, uint64_t seed, const Best& b, uint32_t pixel, uint32_t s,
+                          float band, Path& p, V3& color, Stats& st) {
+    const uint32_t flags = L.flags;
+    if (b.idx >= 0) {
+        const float4 cr = sc.shade[2 * b.idx];
+        const float4 al = sc.shade[2 * b.idx + 1];
+        const uint32_t mat = sc.mat[b.idx];
+        HitInfo h = finish_hit(cr, b.t, p.o, p.d, flags);
+        Rng g = stream_init(seed, pixel, s, p.seg + 1u);
+        V3 nd = scatter(mat, al.w, p.d, h, g, flags, st);
+        p.o = h.p;
+        p.d = nd;
+        if (flags & RT_FLAG_BAND_ALBEDO) p.nb++;
+        else p.thr = v3(p.thr.x * al.x, p.thr.y * al.y, p.thr.z * al.z);
+        p.seg++;
+        color = v3(0.0f, 0.0f, 0.0f);
+        return p.seg == L.max_depth;
+    }
+    if (flags & RT_FLAG_BAND_ALBEDO) {
+        color = sky(p.d, band);
+        for (uint32_t k = 0u; k < p.nb; k++) color = v3(band * color.x, band * color.y, band * color.z);
+    } else {
+        V3 sk = sky(p.d, 0.5f);
+        color = v3(p.thr.x * sk.x, p.thr.y * sk.y, p.thr.z * sk.z);
+    }
+    return true;
+}
+
+RT_DEV float band_of(const RtLaunch& L, uint32_t x) {              // lib.rs:225-226
+    uint32_t gi = L.width / 5u;
+    return 0.1f + 0.2f * (float)(x / (gi ? gi : 1u));
+}
+
+// one finished sample -> the pixel's fixed-point accumulators (acc = the unit's block, pix = pixel of the unit)
+RT_DEV void add_sample(unsigned long long* acc, uint32_t P, uint32_t pix, V3 color) {
+    atomicAdd(acc + pix, (unsigned long long)to_fixed(color.x));
+    atomicAdd(acc + P + pix, (unsigned long long)to_fixed(color.y));
+    atomicAdd(acc + 2u * P + pix, (unsigned long long)to_fixed(color.z));
+}
+
+// Traces and shades the camera rays of samples first .. first+63 of unit `u` (sample i: pixel i % P, sample
+// number i / P).  Called by the whole wavefront.  Finished samples (miss, depth limit, pixel outside the
+// image) are counted in `completed`; the others leave a ray in the queue, packed from slot 0 (`queued`).
+RT_DEV void primary_batch(const Scene& sc, const Tile& tile, const float4* __restrict__ geo0, const RtCamera& cam,
+                          const RtLaunch& L, uint64_t seed, V3 T, const Slot& u, uint32_t slot, uint32_t first,
+                          uint32_t n_samp, unsigned long long* acc, uint32_t* q, Cand& cand,
+                          uint32_t& queued, uint32_t& completed, uint32_t& nseg, Stats& st) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t P = L.unit_w * L.unit_h;
+    const uint32_t sidx = first + lane;
+    const uint32_t pix = sidx & (P - 1u), s = sidx >> L.unit_pshift;
+    const uint32_t dx = pix & (L.unit_w - 1u), dy = pix >> L.unit_shift;
+    const uint32_t x = u.x0 + dx, ly = u.ly0 + dy, y = u.y0 + dy;
+    const bool in_unit = sidx < n_samp;
+    const bool traced = in_unit && x < L.width && ly < L.rows_local && y < L.height;
+    bool done = in_unit && !traced, cont = false;
+    Path p;
+    p.o = p.d = v3(0.0f, 0.0f, 0.0f);
+    uint32_t sphere = 0u;
+    if (traced) {
+        const uint32_t pixel = y * L.width + x;
+        const float band = (L.flags & RT_FLAG_BAND_ALBEDO) ? band_of(L, x) : 0.0f;
+        sample_ray(cam, L, seed, x, y, pixel, s, p.o, p.d);
+        p.thr = v3(1.0f, 1.0f, 1.0f);
+        p.seg = 0u;
+        p.nb = 0u;
+        Best b;
+        b.t = L.t_max;
+        b.idx = -1;
+        scan_primary(geo0, tile, L.n_padded, T, p.o, p.d, vdot(p.d, p.d), L.t_min, b, cand, st);
+        nseg++;
+        sphere = (uint32_t)b.idx;
+        V3 color;
+        if (shade_segment(sc, L, seed, b, pixel, s, band, p, color, st)) {
+            add_sample(acc, P, pix, color);
+            done = true;
+        } else {
+            cont = true;
+        }
+    }
+    const unsigned long long cm = __ballot(cont);
+    if (cont) {
+        const uint32_t r = __builtin_amdgcn_mbcnt_hi((uint32_t)(cm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cm, 0u));
+        q[r] = __float_as_uint(p.o.x); q[64u + r] = __float_as_uint(p.o.y); q[128u + r] = __float_as_uint(p.o.z);
+        q[192u + r] = __float_as_uint(p.d.x); q[256u + r] = __float_as_uint(p.d.y); q[320u + r] = __float_as_uint(p.d.z);
+        q[384u + r] = s;
+        q[448u + r] = ((slot * 64u + pix) << 16) | sphere;
+    }
+    queued = (uint32_t)__popcll(cm);
+    completed = (uint32_t)__popcll(__ballot(done));
+}
+
+RT_DEV void render_queue_body(const Scene& sc, uint32_t* __restrict__ rgba, float4* __restrict__ linear,
+                              unsigned long long* __restrict__ segments, uint32_t* __restrict__ work,
+                              const RtCamera& cam, const RtLaunch& L) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint64_t seed = ((uint64_t)L.seed_hi << 32) | L.seed_lo;
+    const uint32_t flags = L.flags;
+    const uint32_t P = L.unit_w * L.unit_h;
+    const uint32_t n_samp = L.max_depth > 0u ? P * L.samples_per_pixel : 0u;   // per unit
+    const uint32_t S = L.n_padded;
+    const V3 T = ld3(L.translate);
+
+    float4* geo = rt_lds;
+    float4* exa = rt_lds + S;
+    float4* geo0 = rt_lds + 2u * S;
+    char* mine = reinterpret_cast<char*>(geo0 + S) + wave * (RT_Q_CAND_CAP * 128u + 48u * P + RT_Q_WORDS * 256u);
+    Cand cand;
+    cand.col = reinterpret_cast<uint16_t*>(mine) + lane;
+    cand.n = 0u;
+    cand.cap = RT_Q_CAND_CAP;
+    unsigned long long* accum = reinterpret_cast<unsigned long long*>(mine + RT_Q_CAND_CAP * 128u);
+    uint32_t* q = reinterpret_cast<uint32_t*>(mine + RT_Q_CAND_CAP * 128u + 48u * P);
+    for (uint32_t k = lane; k < 6u * P; k += 64u) accum[k] = 0ull;
+    {   // stage the spheres; geo0.w = t + m with the operations of scan_tile for the camera centre as origin
+        const V3 op = vsub(ld3(cam.center), T);
+        const V3 w = v3(2.0f * op.x, 2.0f * op.y, 2.0f * op.z);
+        const float k0 = -(vdot(op, op) * (1.0f - 0x1p-18f));
+        for (uint32_t i = threadIdx.x; i < S; i += blockDim.x) {
+            const float4 c = sc.geom[i];
+            geo[i] = c;
+            exa[i] = sc.exact[i];
+            geo0[i] = make_float4(c.x, c.y, c.z, fmaf(w.z, c.z, fmaf(w.y, c.y, fmaf(w.x, c.x, k0))) + c.w);
+        }
+        __syncthreads();
+    }
+    const Tile tile = {geo, exa};
+
+    Stats st;
+    Slot u0, u1;
+    u0.open = u1.open = false;
+    u0.left = u1.left = 0u;
+    u0.x0 = u0.ly0 = u0.y0 = u1.x0 = u1.ly0 = u1.y0 = 0u;
+    uint32_t cur = 1u;                 // slot whose camera rays are being traced
+    uint32_t next_samp = n_samp;       // its next untraced sample; n_samp: none left (or nothing open yet)
+    bool drained = false;              // the launch's unit counter has run out
+    uint32_t q_head = 0u, q_count = 0u;
+    bool need = true, active = false;
+    Path p;
+    p.o = v3(0.0f, 0.0f, 0.0f); p.d = v3(0.0f, 0.0f, 1.0f); p.thr = v3(1.0f, 1.0f, 1.0f); p.seg = 0u; p.nb = 0u;
+    uint32_t pixel = 0u, s = 0u, pixslot = 0u, nseg = 0u;
+    float band = 0.0f;
+
+    for (;;) {
+        // completed units: write their pixels, free the slot
+        if (u0.open && u0.left == 0u) { write_unit(L, u0, accum, lane, true, rgba, linear); u0.open = false; }
+        if (u1.open && u1.left == 0u) { write_unit(L, u1, accum + 3u * P, lane, true, rgba, linear); u1.open = false; }
+
+        // lanes without a path take queued rays; an empty queue is refilled from the next camera rays
+        for (;;) {
+            const unsigned long long want = __ballot(need);
+            if (want == 0ull) break;
+            if (q_head == q_count) {
+                if (next_samp >= n_samp) {           // this unit's camera rays are all traced: open the next unit
+                    if (u0.open && u0.left == 0u) { write_unit(L, u0, accum, lane, true, rgba, linear); u0.open = false; }
+                    if (u1.open && u1.left == 0u) { write_unit(L, u1, accum + 3u * P, lane, true, rgba, linear); u1.open = false; }
+                    if (drained || (cur ? u0.open : u1.open)) break;
+                    uint32_t unit = 0u;
+                    if (lane == 0u) unit = atomicAdd(work, 1u);
+                    unit = (uint32_t)__builtin_amdgcn_readfirstlane((int)unit);
+                    if (unit >= L.n_units) { drained = true; break; }
+                    cur ^= 1u;
+                    next_samp = 0u;
+                    if (cur) u1 = open_unit(L, unit, n_samp); else u0 = open_unit(L, unit, n_samp);
+                    if (n_samp == 0u) continue;
+                }
+                uint32_t completed = 0u;
+                primary_batch(sc, tile, geo0, cam, L, seed, T, cur ? u1 : u0, cur, next_samp, n_samp,
+                              accum + (cur ? 3u * P : 0u), q, cand, q_count, completed, nseg, st);
+                q_head = 0u;
+                next_samp = next_samp + 64u < n_samp ? next_samp + 64u : n_samp;
+                if (cur) u1.left -= completed; else u0.left -= completed;
+                continue;
+            }
+            const uint32_t j = q_head + __builtin_amdgcn_mbcnt_hi((uint32_t)(want >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)want, 0u));
+            if (need && j < q_count) {
+                p.o = v3(__uint_as_float(q[j]), __uint_as_float(q[64u + j]), __uint_as_float(q[128u + j]));
+                p.d = v3(__uint_as_float(q[192u + j]), __uint_as_float(q[256u + j]), __uint_as_float(q[320u + j]));
+                s = q[384u + j];
+                const uint32_t meta = q[448u + j];
+                const uint32_t sphere = meta & 0xffffu, ps = meta >> 16;
+                const bool in1 = ps >= 64u;
+                const uint32_t pix = ps & 63u;
+                const uint32_t dx = pix & (L.unit_w - 1u), dy = pix >> L.unit_shift;
+                const uint32_t x = (in1 ? u1.x0 : u0.x0) + dx, y = (in1 ? u1.y0 : u0.y0) + dy;
+                pixel = y * L.width + x;
+                pixslot = pix + (in1 ? 3u * P : 0u);
+                p.seg = 1u;
+                if (flags & RT_FLAG_BAND_ALBEDO) {
+                    band = band_of(L, x);
+                    p.nb = 1u;
+                } else {
+                    const float4 al = sc.shade[2u * sphere + 1u];
+                    p.thr = v3(al.x, al.y, al.z);                // 1 * albedo (ray.cu:37)
+                    p.nb = 0u;
+                }
+                need = false;
+                active = true;
+            }
+            const uint32_t asked = (uint32_t)__popcll(want);
+            q_head += asked < q_count - q_head ? asked : q_count - q_head;
+        }
+
+        const bool more = active || q_head < q_count || !drained || next_samp < n_samp || u0.open || u1.open;
+        if (__ballot(more) == 0ull) break;
+
+        bool finished = false;                                   // this lane's path ended in this round
+        if (active) {
+            Best b;
+            b.t = L.t_max;
+            b.idx = -1;
+            scan_tile(tile, S, 0, T, p.o, p.d, vdot(p.d, p.d), L.t_min, b, cand, st);
+            nseg++;
+            V3 color;
+            if (shade_segment(sc, L, seed, b, pixel, s, band, p, color, st)) {
+                add_sample(accum, P, pixslot, color);
+                active = false;
+                need = true;
+                finished = true;
+            }
+        }
+        const unsigned long long fin = __ballot(finished);
+        if (fin != 0ull) {
+            const uint32_t n1 = (uint32_t)__popcll(__ballot(finished && pixslot >= 3u * P));
+            u1.left -= n1;
+            u0.left -= (uint32_t)__popcll(fin) - n1;
+        }
+    }
+
+    if (segments) {
+        unsigned long long n64 = nseg;
+        for (int off = 32; off > 0; off >>= 1) n64 += __shfl_xor(n64, off);
+        if (lane == 0u && n64) atomicAdd(segments, n64);
+#ifdef RT_STATS
+        for (int w = 1; w < 8; w++) {
+            unsigned long long x = st.v[w];
+            for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
+            if (lane == 0u && x) atomicAdd(segments + w, x);
+        }
+        {   // camera-ray batches traced (scan_primary calls)
+            unsigned long long x = st.v[0];
+            for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
+            if (lane == 0u && x) atomicAdd(segments + 15, x);
+        }
+#endif
+    }
+}
+
 extern "C" __global__ void __launch_bounds__(1024)
 rt_render(const float4* geom, const float4* exact, const float4* shade, const uint32_t* mat, uint32_t* rgba,
           float4* linear, unsigned long long* segments, uint32_t* work, RtCamera cam, RtLaunch L) {
     Scene sc = {geom, exact, shade, mat};
     render_body<false>(sc, rgba, linear, segments, work, cam, L);
+}
+
+extern "C" __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(5)))
+rt_render_queue(const float4* geom, const float4* exact, const float4* shade, const uint32_t* mat, uint32_t* rgba,
+                float4* linear, unsigned long long* segments, uint32_t* work, RtCamera cam, RtLaunch L) {
+    Scene sc = {geom, exact, shade, mat};
+    render_queue_body(sc, rgba, linear, segments, work, cam, L);
 }
 
 extern "C" __global__ void __launch_bounds__(1024)

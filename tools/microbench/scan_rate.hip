@@ -84,6 +84,134 @@ __global__ void __launch_bounds__(256) k_packed(const float4* geom, uint32_t* ou
     out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
 }
 
+// camera-ray scan: 5 operations per sphere (t + m precomputed per sphere), 10 LDS reads per 8 spheres
+__global__ void __launch_bounds__(256) k_primary(const float4* geom, uint32_t* out, int reps) {
+    __shared__ float4 geo[N_SPH];
+    __shared__ float4 tm0[N_SPH / 4];
+    for (int i = threadIdx.x; i < N_SPH; i += blockDim.x) { geo[i] = geom[i]; ((float*)tm0)[i] = geom[i].w - 1.0f; }
+    __syncthreads();
+    float ux = 0.6f + threadIdx.x * 1e-4f, uy = 0.0f, uz = 0.8f;
+    uint32_t acc = 0;
+    for (int r = 0; r < reps; r++) {
+        float e = 0.1f + (float)r;
+        for (int blk = 0; blk < N_SPH; blk += 32) {
+            int k = N_SPH - blk < 32 ? N_SPH - blk : 32;
+            uint32_t miss = 0;
+            for (int i = 0; i < k; i += 8) {
+                float4 s[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) s[u] = geo[blk + i + u];
+                float4 ta = tm0[(blk + i) >> 2], tb = tm0[((blk + i) >> 2) + 1];
+                float tm[8] = {ta.x, ta.y, ta.z, ta.w, tb.x, tb.y, tb.z, tb.w};
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    float g = fmaf(uz, s[u].z, fmaf(uy, s[u].y, fmaf(ux, s[u].x, e)));
+                    float key = fmaf(g, g, tm[u]);
+                    miss = __builtin_amdgcn_alignbit(miss, __float_as_uint(key), 31u);
+                }
+            }
+            acc ^= miss;
+        }
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
+}
+
+// the same with two rays per lane: every sphere read serves both
+__global__ void __launch_bounds__(256) k_primary2(const float4* geom, uint32_t* out, int reps) {
+    __shared__ float4 geo[N_SPH];
+    __shared__ float4 tm0[N_SPH / 4];
+    for (int i = threadIdx.x; i < N_SPH; i += blockDim.x) { geo[i] = geom[i]; ((float*)tm0)[i] = geom[i].w - 1.0f; }
+    __syncthreads();
+    float ux = 0.6f + threadIdx.x * 1e-4f, uy = 0.0f, uz = 0.8f, vx = 0.5f, vy = 0.1f + threadIdx.x * 1e-4f, vz = 0.7f;
+    uint32_t acc = 0;
+    for (int r = 0; r < reps; r++) {
+        float e = 0.1f + (float)r, f = 0.2f + (float)r;
+        for (int blk = 0; blk < N_SPH; blk += 32) {
+            int k = N_SPH - blk < 32 ? N_SPH - blk : 32;
+            uint32_t miss = 0, miss2 = 0;
+            for (int i = 0; i < k; i += 8) {
+                float4 s[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) s[u] = geo[blk + i + u];
+                float4 ta = tm0[(blk + i) >> 2], tb = tm0[((blk + i) >> 2) + 1];
+                float tm[8] = {ta.x, ta.y, ta.z, ta.w, tb.x, tb.y, tb.z, tb.w};
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    float g = fmaf(uz, s[u].z, fmaf(uy, s[u].y, fmaf(ux, s[u].x, e)));
+                    float key = fmaf(g, g, tm[u]);
+                    miss = __builtin_amdgcn_alignbit(miss, __float_as_uint(key), 31u);
+                    float g2 = fmaf(vz, s[u].z, fmaf(vy, s[u].y, fmaf(vx, s[u].x, f)));
+                    float key2 = fmaf(g2, g2, tm[u]);
+                    miss2 = __builtin_amdgcn_alignbit(miss2, __float_as_uint(key2), 31u);
+                }
+            }
+            acc ^= miss ^ (miss2 * 3u);
+        }
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
+}
+
+// camera-ray scan with t + m in the sphere's fourth word: 8 LDS reads per 8 spheres
+__global__ void __launch_bounds__(256) k_primary8(const float4* geom, uint32_t* out, int reps) {
+    __shared__ float4 geo[N_SPH];
+    for (int i = threadIdx.x; i < N_SPH; i += blockDim.x) { geo[i] = geom[i]; geo[i].w -= 1.0f; }
+    __syncthreads();
+    float ux = 0.6f + threadIdx.x * 1e-4f, uy = 0.0f, uz = 0.8f;
+    uint32_t acc = 0;
+    for (int r = 0; r < reps; r++) {
+        float e = 0.1f + (float)r;
+        for (int blk = 0; blk < N_SPH; blk += 32) {
+            int k = N_SPH - blk < 32 ? N_SPH - blk : 32;
+            uint32_t miss = 0;
+            for (int i = 0; i < k; i += 8) {
+                float4 s[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) s[u] = geo[blk + i + u];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    float g = fmaf(uz, s[u].z, fmaf(uy, s[u].y, fmaf(ux, s[u].x, e)));
+                    float key = fmaf(g, g, s[u].w);
+                    miss = __builtin_amdgcn_alignbit(miss, __float_as_uint(key), 31u);
+                }
+            }
+            acc ^= miss;
+        }
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
+}
+
+// two rays per lane, t + m in the fourth word
+__global__ void __launch_bounds__(256) k_primary28(const float4* geom, uint32_t* out, int reps) {
+    __shared__ float4 geo[N_SPH];
+    for (int i = threadIdx.x; i < N_SPH; i += blockDim.x) { geo[i] = geom[i]; geo[i].w -= 1.0f; }
+    __syncthreads();
+    float ux = 0.6f + threadIdx.x * 1e-4f, uy = 0.0f, uz = 0.8f, vx = 0.5f, vy = 0.1f + threadIdx.x * 1e-4f, vz = 0.7f;
+    uint32_t acc = 0;
+    for (int r = 0; r < reps; r++) {
+        float e = 0.1f + (float)r, f = 0.2f + (float)r;
+        for (int blk = 0; blk < N_SPH; blk += 32) {
+            int k = N_SPH - blk < 32 ? N_SPH - blk : 32;
+            uint32_t miss = 0, miss2 = 0;
+            for (int i = 0; i < k; i += 8) {
+                float4 s[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) s[u] = geo[blk + i + u];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    float g = fmaf(uz, s[u].z, fmaf(uy, s[u].y, fmaf(ux, s[u].x, e)));
+                    float key = fmaf(g, g, s[u].w);
+                    miss = __builtin_amdgcn_alignbit(miss, __float_as_uint(key), 31u);
+                    float g2 = fmaf(vz, s[u].z, fmaf(vy, s[u].y, fmaf(vx, s[u].x, f)));
+                    float key2 = fmaf(g2, g2, s[u].w);
+                    miss2 = __builtin_amdgcn_alignbit(miss2, __float_as_uint(key2), 31u);
+                }
+            }
+            acc ^= miss ^ (miss2 * 3u);
+        }
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
+}
+
 // LDS side alone: the same eight broadcast ds_read_b128 per step, nothing computed on them
 __global__ void __launch_bounds__(256) k_lds(const float4* geom, uint32_t* out, int reps) {
     __shared__ float4 geo[N_SPH];
@@ -142,6 +270,12 @@ int main() {
         double ms2 = time_ms([&] { hipLaunchKernelGGL(k_packed, dim3(blocks), dim3(256), 0, 0, geom, out, reps); }, 3);
         hipMemcpy(r2.data(), out, r2.size() * 4, hipMemcpyDeviceToHost);
         double ms3 = time_ms([&] { hipLaunchKernelGGL(k_lds, dim3(blocks), dim3(256), 0, 0, geom, out, reps); }, 3);
+        double ms4 = time_ms([&] { hipLaunchKernelGGL(k_primary, dim3(blocks), dim3(256), 0, 0, geom, out, reps); }, 3);
+        double ms5 = time_ms([&] { hipLaunchKernelGGL(k_primary2, dim3(blocks), dim3(256), 0, 0, geom, out, reps); }, 3);
+        double ms6 = time_ms([&] { hipLaunchKernelGGL(k_primary8, dim3(blocks), dim3(256), 0, 0, geom, out, reps); }, 3);
+        double ms7 = time_ms([&] { hipLaunchKernelGGL(k_primary28, dim3(blocks), dim3(256), 0, 0, geom, out, reps); }, 3);
+        printf("waves/SIMD %d: camera-ray scan, t+m in .w: %.2f ms; two rays per lane %.2f ms = %.2f per ray\n", wps, ms6, ms7, ms7 / 2);
+        printf("waves/SIMD %d: camera-ray scan (5 ops) %.2f ms; two rays per lane %.2f ms = %.2f ms per ray\n", wps, ms4, ms5, ms5 / 2);
         size_t diff = 0;
         for (size_t i = 0; i < r1.size(); i++) diff += r1[i] != r2[i];
         double tests = (double)blocks * 256 * reps * N_SPH;
