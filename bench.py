@@ -40,8 +40,9 @@ def parse():
     ap.add_argument("--spp", type=int, default=500)
     ap.add_argument("--depth", type=int, default=50)
     ap.add_argument("--block-dim", type=int, default=0)
-    ap.add_argument("--sample-chunk", type=int, default=2,
-                    help="samples per work item (RtParams.sample_chunk); 0 = the reference's fp32 fold, one lane per pixel")
+    ap.add_argument("--sample-chunk", type=int, default=1,
+                    help="samples per work item (RtParams.sample_chunk); 1 = every sample its own item (camera rays in batches); "
+                         "0 = the reference's fp32 fold, one lane per pixel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-width", type=int, default=1920)
     ap.add_argument("--cpu-spp", type=int, default=32)

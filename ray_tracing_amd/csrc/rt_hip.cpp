@@ -207,7 +207,7 @@ int launch_render(rt_ctx* c, const RtCamera* cam, const RtParams* p, RtLaunch L,
         (uint64_t)P * L.samples_per_pixel < (1ull << 31)) {
         // every sample its own item: camera rays traced in batches, bounce rays from a queue (render_queue_body)
         f = c->f_render_queue;
-        lds = c->n_padded * 48u + waves * (RT_Q_CAND_CAP * 128u + 48u * P + RT_Q_WORDS * 256u);
+        lds = c->n_padded * 32u + waves * (RT_Q_CAND_CAP * 128u + 48u * P + RT_Q_WORDS * 256u);
     } else {
         f = (c->n_padded <= RT_TILE_SPHERES) ? c->f_render : c->f_render_stream;
         lds = (unsigned)lds_bytes(c, block, P);

@@ -184,6 +184,34 @@ def test_chunked_cpu_defaults_and_ragged_edges(oracle, rt, hip):
     check_render(oracle, hip, cam, rt.scene_gpu_default(), rt.DeviceGUI(samples_per_pixel=6, max_depth=0, sample_chunk=2))
 
 
+def test_camera_ray_batches_edge_cases(oracle, rt, hip, monkeypatch):
+    """sample_chunk = 1 runs the kernel that traces camera rays 64 at a time and feeds bounce rays from a queue.
+    Against the checker, bit for bit: the CPU app's defaults (per-column reflectance, rounding quantiser), ragged
+    frame sizes and every block size, the grid sampler, depth limits 0, 1 and 2 (a path that ends at its first
+    hit never enters the queue), a scene without spheres, one sample per pixel, a single row; and the same frame
+    from the item kernel (RT_NO_QUEUE=1) and from other unit shapes."""
+    check_render(oracle, hip, rt.Camera.new_cpu(16.0 / 9.0, 256), rt.scene_cpu_default(), rt.cpu_params(64, 20, seed=0, sample_chunk=1))
+    for width, block in ((250, 64), (67, 1024), (9, 0), (130, 320)):
+        cam = rt.Camera.new(16.0 / 9.0, width)
+        check_render(oracle, hip, cam, rt.scene_gpu_default(),
+                     rt.DeviceGUI(samples_per_pixel=11, max_depth=7, seed=width, block_dim=block, sample_chunk=1))
+    cam = rt.Camera.new(16.0 / 9.0, 100)
+    check_render(oracle, hip, cam, rt.scene_gpu_default(), rt.DeviceGUI(sample2_per_pixel=3, max_depth=5, sample_chunk=1))
+    for depth in (0, 1, 2):
+        check_render(oracle, hip, cam, rt.scene_gpu_default(), rt.DeviceGUI(samples_per_pixel=6, max_depth=depth, sample_chunk=1))
+    check_render(oracle, hip, cam, np.zeros(0, rt.SPHERE_DTYPE), rt.DeviceGUI(samples_per_pixel=3, max_depth=5, sample_chunk=1))
+    sp = rt.scene_book1_final(1)
+    cam = rt.Camera.look_at(16.0 / 9.0, 150, 20.0, (13.0, 2.0, 3.0), (0.0, 0.0, 0.0))
+    p = rt.DeviceGUI(samples_per_pixel=24, max_depth=30, seed=8, sample_chunk=1)
+    got, _ = check_render(oracle, hip, cam, sp, p)
+    check_render(oracle, hip, cam, sp, p, row0=41, rows=1)
+    for env, val in (("RT_NO_QUEUE", "1"), ("RT_UNIT", "8x8"), ("RT_UNIT", "16x1"), ("RT_UNIT", "1x1")):
+        monkeypatch.setenv(env, val)
+        other = hip.render(cam, p, linear=True)
+        monkeypatch.delenv(env)
+        assert np.array_equal(other["linear"], got["linear"]) and other["rays"] == got["rays"]
+
+
 def test_chunked_streaming_kernel(oracle, rt, hip):
     sp = rt.scene_grid(2, 128)
     cam = rt.Camera.look_at(16.0 / 9.0, 480, 40.0, (0.0, 30.0, 80.0), (0.0, 0.0, 0.0))
@@ -192,14 +220,14 @@ def test_chunked_streaming_kernel(oracle, rt, hip):
 
 def test_headline_frame_full_size(oracle, rt, hip):
     """The configuration the metric is quoted on, in full: book-1 final scene, 3840x2160, 500 spp, depth 50,
-    sample_chunk 2 (what bench.py times).  The whole frame is rendered once on the GPU; the checker renders
+    sample_chunk 1 (what bench.py times: camera rays traced in batches, bounce rays from the queue).  The whole frame is rendered once on the GPU; the checker renders
     three bands of rows of the same frame (the RNG is keyed on the global pixel index, so a band of the full
     frame is a well-defined sub-problem) and every bit of them must agree.  Size-independent properties on
     the rest: every pixel finite and opaque, the fold-order render of one band within rounding of it, and
     the per-band ray counts of separate launches add up inside the frame's count."""
     sp = rt.scene_book1_final(1)
     cam = rt.Camera.look_at(16.0 / 9.0, 3840, 20.0, (13.0, 2.0, 3.0), (0.0, 0.0, 0.0))
-    p = rt.DeviceGUI(samples_per_pixel=500, max_depth=50, seed=1, sample_chunk=2)
+    p = rt.DeviceGUI(samples_per_pixel=500, max_depth=50, seed=1, sample_chunk=1)
     hip.upload_scene(sp)
     full = hip.render(cam, p, linear=True)
     assert full["linear"].shape == (2160, 3840, 4) and np.isfinite(full["linear"]).all()
@@ -244,7 +272,7 @@ def test_c5_full_size(oracle, rt, hip):
     sp = rt.scene_mirror_hall(3, 64)
     cam = rt.Camera.look_at(16.0 / 9.0, 7680, 90.0, (0.0, 0.0, -85.0), (0.0, 0.0, -70.0))
     assert cam.image_height == 4320
-    p = rt.DeviceGUI(samples_per_pixel=256, max_depth=100, seed=1, sample_chunk=2)
+    p = rt.DeviceGUI(samples_per_pixel=256, max_depth=100, seed=1, sample_chunk=1)
     hip.upload_scene(sp)
     full = hip.render(cam, p)
     assert (full["rgba"][..., 3] == 255).all() and full["rays"] > 7680 * 4320 * 256 * 2
