@@ -136,7 +136,7 @@ def main():
     if rank == 0:
         n_sph = len(spheres)
         flop_per_segment = 18 * n_sph + 64
-        # dominant kernel = rt_render on this rank: its own segments over its own average duration
+        # dominant kernel = the render kernel on this rank: its own segments over its own average duration
         rank0_rays_per_launch = rays_total / max(1, args.steps)
         k_ms = sum(kernel_ms) / max(1, len(kernel_ms))
         achieved = rank0_rays_per_launch * flop_per_segment / (k_ms * 1e-3) * 1e-12 if k_ms > 0 else 0.0
@@ -167,7 +167,7 @@ def main():
                        "segments_per_frame": rays_all / max(1, args.steps), "parallelism": f"rowtiles{world}"},
             "roofline": {"bound": "valu_fp32", "achieved": achieved, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP32_VECTOR_PEAK_TFLOPS, "traffic": traffic,
-                         "kernel": "rt_render", "kernel_ms": k_ms, "flop_per_segment": flop_per_segment,
+                         "kernel": hip.last_kernel_name(), "kernel_ms": k_ms, "flop_per_segment": flop_per_segment,
                          "segments_per_launch": rank0_rays_per_launch},
             "kernel_ms_max_over_ranks": kms_max,
             "checksum": int(frame.to(torch.int64).sum().item()) if frame is not None else None,

@@ -290,6 +290,9 @@ class HipWorld:
         self._check(self._lib.rt_show_random(self._ctx, width, height, seed, int(norm), _ffi.ptr(out)))
         return out
 
+    def last_kernel_name(self):
+        return (self._lib.rt_last_kernel_name(self._ctx) or b"").decode()
+
     def debug_counters(self):
         out = (C.c_uint64 * 16)()
         self._check(self._lib.rt_debug_counters(self._ctx, C.byref(out)))

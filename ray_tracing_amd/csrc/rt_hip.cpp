@@ -49,6 +49,7 @@ struct rt_ctx {
     void *d_tiles = nullptr, *d_frame = nullptr;     // rank's tile buffer (rank 0: all ranks' buffers), assembled frame
     size_t cap_tiles = 0, cap_frame = 0;
     float last_ms = 0.0f;
+    const char* last_kernel = "";
     int compute_units = 0, clock_khz = 0;
     char name[600] = {0};
     std::string err;
@@ -207,9 +208,11 @@ int launch_render(rt_ctx* c, const RtCamera* cam, const RtParams* p, RtLaunch L,
         (uint64_t)P * L.samples_per_pixel < (1ull << 31)) {
         // every sample its own item: camera rays traced in batches, bounce rays from a queue (render_queue_body)
         f = c->f_render_queue;
+        c->last_kernel = "rt_render_queue";
         lds = c->n_padded * 32u + waves * (RT_Q_CAND_CAP * 128u + 48u * P + RT_Q_WORDS * 256u);
     } else {
         f = (c->n_padded <= RT_TILE_SPHERES) ? c->f_render : c->f_render_stream;
+        c->last_kernel = (c->n_padded <= RT_TILE_SPHERES) ? "rt_render" : "rt_render_stream";
         lds = (unsigned)lds_bytes(c, block, P);
     }
     // The wavefronts take units from a counter until none are left, so the grid only has to fill the GPU
@@ -518,6 +521,8 @@ int rt_show_random(rt_ctx* c, uint32_t width, uint32_t height, uint64_t seed, in
 }
 
 float rt_last_kernel_ms(const rt_ctx* c) { return c ? c->last_ms : 0.0f; }
+
+const char* rt_last_kernel_name(const rt_ctx* c) { return c ? c->last_kernel : ""; }
 
 int rt_debug_counters(rt_ctx* c, uint64_t out[16]) {
     if (!c || !out) return RT_ERR_INVALID;

@@ -14,9 +14,10 @@ with open(stats) as f, open(os.path.join(dst, f"{tag}_kernel_stats.csv"), "w") a
         row[0] = row[0][:80]
         g.write(",".join(f'"{c}"' for c in row) + "\n")
 trace = glob.glob(os.path.join(src, "trace", "**", "*kernel_trace.csv"), recursive=True)[0]
-durs = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in csv.DictReader(open(trace)) if r["Kernel_Name"] == "rt_render"]
 bench_line = [l for l in open(os.path.join(src, "trace.log")) if l.startswith("{")][-1]
 bench = json.loads(bench_line)
+KERNEL = bench["roofline"]["kernel"]
+durs = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in csv.DictReader(open(trace)) if r["Kernel_Name"] == KERNEL]
 
 # 2. PMC passes
 pmc = collections.defaultdict(float)
@@ -24,7 +25,7 @@ meta = {}
 for f in glob.glob(os.path.join(src, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
     per = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
-        if r["Kernel_Name"] != "rt_render":
+        if r["Kernel_Name"] != KERNEL:
             continue
         per[(r["Counter_Name"], r["Dispatch_Id"])].append(float(r["Counter_Value"]))
         meta = {"VGPR_Count": r["VGPR_Count"], "SGPR_Count": r["SGPR_Count"], "Workgroup_Size": r["Workgroup_Size"], "Grid_Size": r["Grid_Size"]}
@@ -38,7 +39,7 @@ seg = bench["roofline"]["segments_per_launch"]
 lines = []
 w = lines.append
 w(f"# {tag}: rocprofv3 summary of `python bench.py` (book-1 final scene, 3840x2160, 500 spp, depth 50, 1 x MI355X)")
-w(f"kernel-trace: rt_render {len(durs)} dispatches, durations ms {['%.1f' % d for d in durs]}, average {sum(durs) / len(durs):.1f} ms")
+w(f"kernel-trace: {KERNEL} {len(durs)} dispatches, durations ms {['%.1f' % d for d in durs]}, average {sum(durs) / len(durs):.1f} ms")
 w(f"bench.py in the same run: kernel_ms {bench['roofline']['kernel_ms']:.1f} (HIP events in the library), value {bench['value']:.1f} Mrays/s, "
   f"roofline {bench['roofline']['achieved']:.2f} TFLOP/s = {100 * bench['roofline']['frac']:.1f} % of {bench['roofline']['peak']}")
 w(f"dispatch: {meta}")
@@ -50,7 +51,7 @@ w("")
 w("derived:")
 if pmc.get("SQ_INSTS_VALU"):
     w(f"  ray segments per launch            {seg:.0f}")
-    w(f"  VALU wave-instructions per segment {pmc['SQ_INSTS_VALU'] / seg * 64:.1f} per 64-lane wavefront pass (scan floor 488 x 9 = 4392)")
+    w(f"  VALU wave-instructions per segment {pmc['SQ_INSTS_VALU'] / seg * 64:.1f} x 64 (the item kernel's trip: 488 x 9 = 4392 in the scan; camera rays 488 x 5)")
     w(f"  active lanes per VALU instruction  {pmc['SQ_THREAD_CYCLES_VALU'] / pmc['SQ_INSTS_VALU']:.1f} of 64 ({100 * pmc['SQ_THREAD_CYCLES_VALU'] / pmc['SQ_INSTS_VALU'] / 64:.1f} %)")
     w(f"  LDS instructions per VALU instr    {pmc['SQ_INSTS_LDS'] / pmc['SQ_INSTS_VALU']:.3f}")
     w(f"  SALU instructions per VALU instr   {pmc['SQ_INSTS_SALU'] / pmc['SQ_INSTS_VALU']:.3f}")
