@@ -212,6 +212,40 @@ def test_camera_ray_batches_edge_cases(oracle, rt, hip, monkeypatch):
         assert np.array_equal(other["linear"], got["linear"]) and other["rays"] == got["rays"]
 
 
+def test_randomised_scenes_all_modes(oracle, rt, hip):
+    """Seeded random scenes (overlapping spheres, tiny and huge radii, all three materials, cameras inside and
+    outside the cloud), random frame sizes, samplers, depths, block sizes and accumulation modes
+    (fold / every sample its own item / runs of 3): every case bit for bit against the checker."""
+    rng = np.random.default_rng(20250611)
+    for case in range(48):
+        n = int(rng.choice([1, 2, 7, 8, 9, 33, 200, 1030]))
+        sp = np.zeros(n, rt.SPHERE_DTYPE)
+        sp["center"] = rng.uniform(-6, 6, (n, 3)).astype(np.float32)
+        sp["radius"] = np.exp(rng.uniform(np.log(0.05), np.log(3.0), n)).astype(np.float32)
+        if case % 5 == 0:
+            sp["center"][0] = (0.0, -1000.0, 0.0); sp["radius"][0] = 1000.0          # ground
+        sp["material"] = rng.choice([1, 2, 3], n, p=[0.5, 0.3, 0.2])
+        sp["albedo"] = rng.uniform(0.1, 1.0, (n, 3)).astype(np.float32)
+        sp["param"] = np.where(sp["material"] == 3, 1.5, rng.uniform(0.0, 1.0, n)).astype(np.float32)
+        width = int(rng.integers(5, 97))
+        cam = rt.Camera.look_at(float(rng.choice([16 / 9, 1.0, 2.5])), width, float(rng.uniform(20, 100)),
+                                tuple(rng.uniform(-8, 8, 3)), tuple(rng.uniform(-1, 1, 3)))
+        chunk = int(rng.choice([0, 1, 1, 3]))
+        if rng.random() < 0.3:
+            n2 = int(rng.integers(1, 4))
+            p = rt.DeviceGUI(sample2_per_pixel=n2, max_depth=int(rng.integers(1, 12)), seed=case, sample_chunk=chunk,
+                             block_dim=int(rng.choice([0, 64, 192, 1024])))
+        else:
+            p = rt.DeviceGUI(samples_per_pixel=int(rng.integers(1, 10)), max_depth=int(rng.integers(1, 40)), seed=case,
+                             sample_chunk=chunk, block_dim=int(rng.choice([0, 64, 192, 1024])))
+        H = cam.image_height
+        if case % 3 == 0 and H > 3:
+            row0 = int(rng.integers(0, H - 2)); rows = int(rng.integers(1, H - row0 + 1))
+            check_render(oracle, hip, cam, sp, p, row0=row0, rows=rows)
+        else:
+            check_render(oracle, hip, cam, sp, p)
+
+
 def test_chunked_streaming_kernel(oracle, rt, hip):
     sp = rt.scene_grid(2, 128)
     cam = rt.Camera.look_at(16.0 / 9.0, 480, 40.0, (0.0, 30.0, 80.0), (0.0, 0.0, 0.0))
