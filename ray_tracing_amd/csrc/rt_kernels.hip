@@ -838,6 +838,9 @@ RT_DEV void primary_batch(const Scene& sc, const Tile& tile, const float4* __res
         b.t = L.t_max;
         b.idx = -1;
         scan_primary(geo0, tile, L.n_padded, T, p.o, p.d, vdot(p.d, p.d), L.t_min, b, cand, st);
+#ifdef RT_EXP_PRIMARY2
+        scan_primary(geo0, tile, L.n_padded, T, p.o, p.d, vdot(p.d, p.d), L.t_min, b, cand, st);   // cost experiment: changes nothing (strict bound)
+#endif
         nseg++;
         sphere = (uint32_t)b.idx;
         V3 color;
