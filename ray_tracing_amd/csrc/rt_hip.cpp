@@ -35,7 +35,7 @@ struct rt_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipModule_t module = nullptr;
-    hipFunction_t f_render = nullptr, f_render_queue = nullptr, f_render_stream = nullptr, f_hits = nullptr, f_random = nullptr, f_assemble = nullptr;
+    hipFunction_t f_render = nullptr, f_render_queue = nullptr, f_render_stream = nullptr, f_render_queue_stream = nullptr, f_hits = nullptr, f_random = nullptr, f_assemble = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     void *d_geom = nullptr, *d_exact = nullptr, *d_shade = nullptr, *d_mat = nullptr;
     float translate[3] = {0.0f, 0.0f, 0.0f};
@@ -86,10 +86,11 @@ int ensure(rt_ctx* c, void** p, size_t* cap, size_t bytes) {
 int load_image(rt_ctx* c, const void* image) {
     hipModule_t m = nullptr;
     RT_HIP(c, hipModuleLoadData(&m, image));
-    hipFunction_t fr, fq, fs, fh, fx, fa;
+    hipFunction_t fr, fq, fs, fqs, fh, fx, fa;
     hipError_t e;
     if ((e = hipModuleGetFunction(&fr, m, "rt_render")) != hipSuccess ||
         (e = hipModuleGetFunction(&fq, m, "rt_render_queue")) != hipSuccess ||
+        (e = hipModuleGetFunction(&fqs, m, "rt_render_queue_stream")) != hipSuccess ||
         (e = hipModuleGetFunction(&fs, m, "rt_render_stream")) != hipSuccess ||
         (e = hipModuleGetFunction(&fh, m, "rt_primary_hits")) != hipSuccess ||
         (e = hipModuleGetFunction(&fx, m, "rt_show_random")) != hipSuccess ||
@@ -99,7 +100,7 @@ int load_image(rt_ctx* c, const void* image) {
     }
     if (c->module) (void)hipModuleUnload(c->module);
     c->module = m;
-    c->f_render = fr; c->f_render_queue = fq; c->f_render_stream = fs; c->f_hits = fh; c->f_random = fx; c->f_assemble = fa;
+    c->f_render = fr; c->f_render_queue = fq; c->f_render_queue_stream = fqs; c->f_render_stream = fs; c->f_hits = fh; c->f_random = fx; c->f_assemble = fa;
     return 0;
 }
 
@@ -204,12 +205,13 @@ int launch_render(rt_ctx* c, const RtCamera* cam, const RtParams* p, RtLaunch L,
     hipFunction_t f;
     unsigned lds;
     const char* mode = std::getenv("RT_NO_QUEUE");           // experiments: keep sample_chunk = 1 on the item kernel
-    if (c->n_padded <= RT_TILE_SPHERES && L.n_chunks > 1 && L.chunk == 1 && !(mode && *mode == '1') &&
-        (uint64_t)P * L.samples_per_pixel < (1ull << 31)) {
-        // every sample its own item: camera rays traced in batches, bounce rays from a queue (render_queue_body)
-        f = c->f_render_queue;
-        c->last_kernel = "rt_render_queue";
-        lds = c->n_padded * 32u + waves * (RT_Q_CAND_CAP * 128u + 48u * P + RT_Q_WORDS * 256u);
+    if (L.n_chunks > 1 && L.chunk == 1 && !(mode && *mode == '1') && (uint64_t)P * L.samples_per_pixel < (1ull << 31) &&
+        c->n_padded <= 65536u) {                                 // a queued ray names the sphere it left in 16 bits
+        // every sample its own item: camera rays traced in batches, bounce rays from a queue
+        const bool one_tile = c->n_padded <= RT_TILE_SPHERES;
+        f = one_tile ? c->f_render_queue : c->f_render_queue_stream;
+        c->last_kernel = one_tile ? "rt_render_queue" : "rt_render_queue_stream";
+        lds = (one_tile ? c->n_padded : RT_TILE_SPHERES) * 32u + waves * (RT_Q_CAND_CAP * 128u + 48u * P + RT_Q_WORDS * 256u);
     } else {
         f = (c->n_padded <= RT_TILE_SPHERES) ? c->f_render : c->f_render_stream;
         c->last_kernel = (c->n_padded <= RT_TILE_SPHERES) ? "rt_render" : "rt_render_stream";

@@ -266,7 +266,7 @@ RT_DEV void scan_tile(const Tile& tile, uint32_t count, int base, V3 T,
 // 16-byte LDS read per sphere, as in scan_tile) and the scan is g (3 fma), key = fma(g, g, t + m) (1) and the sign
 // bit (1): 5 operations per sphere and lane instead of 9.  One rounding moves from the end of the chain to
 // that number; the bound of scan_tile's derivation and its slack are unchanged.
-RT_DEV void scan_primary(const float4* __restrict__ geo0, const Tile& tile, uint32_t count, V3 T,
+RT_DEV void scan_primary(const float4* __restrict__ geo0, const Tile& tile, uint32_t count, int base, V3 T,
                          V3 o, V3 d, float a, float t_min, Best& b, Cand& c, Stats& st) {
     st.wave(0);
     const V3 op = vsub(o, T);
@@ -287,9 +287,9 @@ RT_DEV void scan_primary(const float4* __restrict__ geo0, const Tile& tile, uint
                 miss = __builtin_amdgcn_alignbit(miss, __float_as_uint(key), 31u);
             }
         }
-        decode_block(tile, 0, blk, k, miss, o, d, a, t_min, b, c, st);
+        decode_block(tile, base, blk, k, miss, o, d, a, t_min, b, c, st);
     }
-    drain(tile, 0, c, o, d, a, t_min, b, st);
+    drain(tile, base, c, o, d, a, t_min, b, st);
 }
 
 // ---------------------------------------------------------------- shading
@@ -837,9 +837,9 @@ RT_DEV void primary_batch(const Scene& sc, const Tile& tile, const float4* __res
         Best b;
         b.t = L.t_max;
         b.idx = -1;
-        scan_primary(geo0, tile, L.n_padded, T, p.o, p.d, vdot(p.d, p.d), L.t_min, b, cand, st);
+        scan_primary(geo0, tile, L.n_padded, 0, T, p.o, p.d, vdot(p.d, p.d), L.t_min, b, cand, st);
 #ifdef RT_EXP_PRIMARY2
-        scan_primary(geo0, tile, L.n_padded, T, p.o, p.d, vdot(p.d, p.d), L.t_min, b, cand, st);   // cost experiment: changes nothing (strict bound)
+        scan_primary(geo0, tile, L.n_padded, 0, T, p.o, p.d, vdot(p.d, p.d), L.t_min, b, cand, st);   // cost experiment: changes nothing (strict bound)
 #endif
         nseg++;
         sphere = (uint32_t)b.idx;
@@ -1020,6 +1020,206 @@ RT_DEV void render_queue_body(const Scene& sc, uint32_t* __restrict__ rgba, floa
     }
 }
 
+// The same for sphere lists beyond one LDS tile.  The workgroup streams the tiles in lock step, as
+// render_body<true> does; in every round each wavefront either traces its next 64 camera rays (scan_primary on
+// the tile's geo0 copy) or one segment of its bounce rays (scan_tile), whichever keeps its lanes busy: camera
+// rays when a lane is out of work and the queue is empty, bounce rays otherwise.
+//   LDS: [geo S float4][geo0 S float4], S = RT_TILE_SPHERES, then per wavefront as in render_queue_body.
+RT_DEV void render_queue_stream_body(const Scene& sc, uint32_t* __restrict__ rgba, float4* __restrict__ linear,
+                                     unsigned long long* __restrict__ segments, uint32_t* __restrict__ work,
+                                     const RtCamera& cam, const RtLaunch& L) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint64_t seed = ((uint64_t)L.seed_hi << 32) | L.seed_lo;
+    const uint32_t flags = L.flags;
+    const uint32_t P = L.unit_w * L.unit_h;
+    const uint32_t n_samp = L.max_depth > 0u ? P * L.samples_per_pixel : 0u;   // per unit
+    const uint32_t S = tile_capacity(L);
+    const V3 T = ld3(L.translate);
+
+    float4* geo = rt_lds;
+    float4* geo0 = rt_lds + S;
+    char* mine = reinterpret_cast<char*>(geo0 + S) + wave * (RT_Q_CAND_CAP * 128u + 48u * P + RT_Q_WORDS * 256u);
+    Cand cand;
+    cand.col = reinterpret_cast<uint16_t*>(mine) + lane;
+    cand.n = 0u;
+    cand.cap = RT_Q_CAND_CAP;
+    unsigned long long* accum = reinterpret_cast<unsigned long long*>(mine + RT_Q_CAND_CAP * 128u);
+    uint32_t* q = reinterpret_cast<uint32_t*>(mine + RT_Q_CAND_CAP * 128u + 48u * P);
+    for (uint32_t k = lane; k < 6u * P; k += 64u) accum[k] = 0ull;
+    // camera-centre constants of geo0.w = t + m (operations of scan_tile)
+    const V3 op0 = vsub(ld3(cam.center), T);
+    const V3 w0 = v3(2.0f * op0.x, 2.0f * op0.y, 2.0f * op0.z);
+    const float k00 = -(vdot(op0, op0) * (1.0f - 0x1p-18f));
+
+    Stats st;
+    Slot u0, u1;
+    u0.open = u1.open = false;
+    u0.left = u1.left = 0u;
+    u0.x0 = u0.ly0 = u0.y0 = u1.x0 = u1.ly0 = u1.y0 = 0u;
+    uint32_t cur = 1u, next_samp = n_samp;
+    bool drained = false;
+    uint32_t q_head = 0u, q_count = 0u;
+    bool need = true, active = false;
+    Path p;
+    p.o = v3(0.0f, 0.0f, 0.0f); p.d = v3(0.0f, 0.0f, 1.0f); p.thr = v3(1.0f, 1.0f, 1.0f); p.seg = 0u; p.nb = 0u;
+    uint32_t pixel = 0u, s = 0u, pixslot = 0u, nseg = 0u;
+    float band = 0.0f;
+
+    for (;;) {
+        if (u0.open && u0.left == 0u) { write_unit(L, u0, accum, lane, true, rgba, linear); u0.open = false; }
+        if (u1.open && u1.left == 0u) { write_unit(L, u1, accum + 3u * P, lane, true, rgba, linear); u1.open = false; }
+
+        // lanes without a path take queued rays
+        unsigned long long want = __ballot(need);
+        if (want != 0ull && q_head < q_count) {
+            const uint32_t j = q_head + __builtin_amdgcn_mbcnt_hi((uint32_t)(want >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)want, 0u));
+            if (need && j < q_count) {
+                p.o = v3(__uint_as_float(q[j]), __uint_as_float(q[64u + j]), __uint_as_float(q[128u + j]));
+                p.d = v3(__uint_as_float(q[192u + j]), __uint_as_float(q[256u + j]), __uint_as_float(q[320u + j]));
+                s = q[384u + j];
+                const uint32_t meta = q[448u + j];
+                const uint32_t sphere = meta & 0xffffu, ps = meta >> 16;
+                const bool in1 = ps >= 64u;
+                const uint32_t pix = ps & 63u;
+                const uint32_t dx = pix & (L.unit_w - 1u), dy = pix >> L.unit_shift;
+                const uint32_t x = (in1 ? u1.x0 : u0.x0) + dx, y = (in1 ? u1.y0 : u0.y0) + dy;
+                pixel = y * L.width + x;
+                pixslot = pix + (in1 ? 3u * P : 0u);
+                p.seg = 1u;
+                if (flags & RT_FLAG_BAND_ALBEDO) {
+                    band = band_of(L, x);
+                    p.nb = 1u;
+                } else {
+                    const float4 al = sc.shade[2u * sphere + 1u];
+                    p.thr = v3(al.x, al.y, al.z);
+                    p.nb = 0u;
+                }
+                need = false;
+                active = true;
+            }
+            const uint32_t asked = (uint32_t)__popcll(want);
+            q_head += asked < q_count - q_head ? asked : q_count - q_head;
+            want = __ballot(need);
+        }
+        // a lane still without work and nothing queued: this round goes to the next camera rays
+        bool primary = false;
+        if (want != 0ull && q_head == q_count) {
+            if (next_samp >= n_samp && !drained && !(cur ? u0.open : u1.open)) {
+                uint32_t unit = 0u;
+                if (lane == 0u) unit = atomicAdd(work, 1u);
+                unit = (uint32_t)__builtin_amdgcn_readfirstlane((int)unit);
+                if (unit >= L.n_units) {
+                    drained = true;
+                } else {
+                    cur ^= 1u;
+                    next_samp = 0u;
+                    if (cur) u1 = open_unit(L, unit, n_samp); else u0 = open_unit(L, unit, n_samp);
+                }
+            }
+            primary = next_samp < n_samp;
+        }
+        const bool more = active || q_head < q_count || !drained || next_samp < n_samp || u0.open || u1.open;
+        if (!__syncthreads_or(more ? 1 : 0)) break;
+
+        // this round's ray per lane: a camera ray of the batch, or the lane's bounce ray
+        const Slot& u = cur ? u1 : u0;
+        uint32_t bpix = 0u, bs = 0u, bpixel = 0u;
+        float bband = 0.0f;
+        bool bdone = false, traced = false;
+        Path bp;
+        bp.o = bp.d = v3(0.0f, 0.0f, 0.0f); bp.thr = v3(1.0f, 1.0f, 1.0f); bp.seg = 0u; bp.nb = 0u;
+        if (primary) {
+            const uint32_t sidx = next_samp + lane;
+            bpix = sidx & (P - 1u);
+            bs = sidx >> L.unit_pshift;
+            const uint32_t dx = bpix & (L.unit_w - 1u), dy = bpix >> L.unit_shift;
+            const uint32_t x = u.x0 + dx, ly = u.ly0 + dy, y = u.y0 + dy;
+            const bool in_unit = sidx < n_samp;
+            traced = in_unit && x < L.width && ly < L.rows_local && y < L.height;
+            bdone = in_unit && !traced;
+            if (traced) {
+                bpixel = y * L.width + x;
+                if (flags & RT_FLAG_BAND_ALBEDO) bband = band_of(L, x);
+                sample_ray(cam, L, seed, x, y, bpixel, bs, bp.o, bp.d);
+            }
+        }
+        const bool scanning = primary ? traced : active;
+        const V3 ro = primary ? bp.o : p.o, rd = primary ? bp.d : p.d;
+        const float ra = vdot(rd, rd);
+        Best b;
+        b.t = L.t_max;
+        b.idx = -1;
+        for (uint32_t first = 0u; first < L.n_padded; first += RT_TILE_SPHERES) {
+            uint32_t count = L.n_padded - first;
+            if (count > RT_TILE_SPHERES) count = RT_TILE_SPHERES;
+            if (first) __syncthreads();                          // previous tile fully scanned
+            for (uint32_t i = threadIdx.x; i < count; i += blockDim.x) {
+                const float4 c = sc.geom[first + i];
+                geo[i] = c;
+                geo0[i] = make_float4(c.x, c.y, c.z, fmaf(w0.z, c.z, fmaf(w0.y, c.y, fmaf(w0.x, c.x, k00))) + c.w);
+            }
+            __syncthreads();
+            const Tile tile = {geo, sc.exact + first};           // exact-test data from global memory
+            if (scanning) {
+                if (primary) scan_primary(geo0, tile, count, (int)first, T, ro, rd, ra, L.t_min, b, cand, st);
+                else scan_tile(tile, count, (int)first, T, ro, rd, ra, L.t_min, b, cand, st);
+            }
+        }
+
+        bool finished = false;                                   // a bounce path of this lane ended in this round
+        if (primary) {
+            bool cont = false;
+            uint32_t sphere = 0u;
+            if (traced) {
+                nseg++;
+                sphere = (uint32_t)b.idx;
+                V3 color;
+                if (shade_segment(sc, L, seed, b, bpixel, bs, bband, bp, color, st)) {
+                    add_sample(accum + (cur ? 3u * P : 0u), P, bpix, color);
+                    bdone = true;
+                } else {
+                    cont = true;
+                }
+            }
+            const unsigned long long cm = __ballot(cont);
+            if (cont) {
+                const uint32_t r = __builtin_amdgcn_mbcnt_hi((uint32_t)(cm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cm, 0u));
+                q[r] = __float_as_uint(bp.o.x); q[64u + r] = __float_as_uint(bp.o.y); q[128u + r] = __float_as_uint(bp.o.z);
+                q[192u + r] = __float_as_uint(bp.d.x); q[256u + r] = __float_as_uint(bp.d.y); q[320u + r] = __float_as_uint(bp.d.z);
+                q[384u + r] = bs;
+                q[448u + r] = ((cur * 64u + bpix) << 16) | sphere;
+            }
+            q_head = 0u;
+            q_count = (uint32_t)__popcll(cm);
+            const uint32_t completed = (uint32_t)__popcll(__ballot(bdone));
+            if (cur) u1.left -= completed; else u0.left -= completed;
+            next_samp = next_samp + 64u < n_samp ? next_samp + 64u : n_samp;
+        } else if (active) {
+            nseg++;
+            V3 color;
+            if (shade_segment(sc, L, seed, b, pixel, s, band, p, color, st)) {
+                add_sample(accum, P, pixslot, color);
+                active = false;
+                need = true;
+                finished = true;
+            }
+        }
+        const unsigned long long fin = __ballot(finished);
+        if (fin != 0ull) {
+            const uint32_t n1 = (uint32_t)__popcll(__ballot(finished && pixslot >= 3u * P));
+            u1.left -= n1;
+            u0.left -= (uint32_t)__popcll(fin) - n1;
+        }
+    }
+
+    if (segments) {
+        unsigned long long n64 = nseg;
+        for (int off = 32; off > 0; off >>= 1) n64 += __shfl_xor(n64, off);
+        if (lane == 0u && n64) atomicAdd(segments, n64);
+    }
+}
+
 extern "C" __global__ void __launch_bounds__(1024)
 rt_render(const float4* geom, const float4* exact, const float4* shade, const uint32_t* mat, uint32_t* rgba,
           float4* linear, unsigned long long* segments, uint32_t* work, RtCamera cam, RtLaunch L) {
@@ -1032,6 +1232,13 @@ rt_render_queue(const float4* geom, const float4* exact, const float4* shade, co
                 float4* linear, unsigned long long* segments, uint32_t* work, RtCamera cam, RtLaunch L) {
     Scene sc = {geom, exact, shade, mat};
     render_queue_body(sc, rgba, linear, segments, work, cam, L);
+}
+
+extern "C" __global__ void __launch_bounds__(1024)
+rt_render_queue_stream(const float4* geom, const float4* exact, const float4* shade, const uint32_t* mat, uint32_t* rgba,
+                       float4* linear, unsigned long long* segments, uint32_t* work, RtCamera cam, RtLaunch L) {
+    Scene sc = {geom, exact, shade, mat};
+    render_queue_stream_body(sc, rgba, linear, segments, work, cam, L);
 }
 
 extern "C" __global__ void __launch_bounds__(1024)

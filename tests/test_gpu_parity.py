@@ -290,7 +290,7 @@ def test_c4_full_size(oracle, rt, hip):
     segment): the whole frame on the GPU, one row of it bit-exact against the checker."""
     sp = rt.scene_grid(2, 128)
     cam = rt.Camera.look_at(16.0 / 9.0, 1920, 40.0, (0.0, 30.0, 80.0), (0.0, 0.0, 0.0))
-    p = rt.DeviceGUI(samples_per_pixel=64, max_depth=16, seed=1, sample_chunk=2)
+    p = rt.DeviceGUI(samples_per_pixel=64, max_depth=16, seed=1, sample_chunk=1)
     hip.upload_scene(sp)
     full = hip.render(cam, p, linear=True)
     assert np.isfinite(full["linear"]).all() and full["rays"] > 1920 * 1080 * 64 * 3
