@@ -41,13 +41,20 @@ typedef struct RtLaunch {
 // workgroup; larger ones are streamed through the same buffer tile by tile.  A bigger tile means fewer
 // barriers per path segment but fewer workgroups per CU: on the 16,385-sphere scene 512 and 1024 run at
 // 232 Mrays/s, 2048 (two workgroups per CU) at 169.
+#ifndef RT_TILE_SPHERES
 #define RT_TILE_SPHERES 1024u
+#endif
 // Candidate slots per lane (u16 each, in LDS); a wavefront drains its lists as soon as one lane's list
 // is full (checked after every push, so a list can never overflow).
 #ifndef RT_CAND_CAP
 #define RT_CAND_CAP 16u
 #endif
 // Kernel for sample_chunk = 1 (camera rays in batches): candidate slots per lane, 32-bit words per queued ray
+// spheres per LDS tile when that kernel streams a longer list (more workgroups per CU than with a full tile:
+// measured on the 16,385-sphere scene, 512: 1,265 ms, 1024: 1,341 ms, 2048: 1,748 ms)
+#ifndef RT_Q_STREAM_TILE
+#define RT_Q_STREAM_TILE 512u
+#endif
 #define RT_Q_CAND_CAP 8u
 #define RT_Q_WORDS 8u
 

@@ -211,7 +211,7 @@ int launch_render(rt_ctx* c, const RtCamera* cam, const RtParams* p, RtLaunch L,
         const bool one_tile = c->n_padded <= RT_TILE_SPHERES;
         f = one_tile ? c->f_render_queue : c->f_render_queue_stream;
         c->last_kernel = one_tile ? "rt_render_queue" : "rt_render_queue_stream";
-        lds = (one_tile ? c->n_padded : RT_TILE_SPHERES) * 32u + waves * (RT_Q_CAND_CAP * 128u + 48u * P + RT_Q_WORDS * 256u);
+        lds = (one_tile ? c->n_padded : RT_Q_STREAM_TILE) * 32u + waves * (RT_Q_CAND_CAP * 128u + 48u * P + RT_Q_WORDS * 256u);
     } else {
         f = (c->n_padded <= RT_TILE_SPHERES) ? c->f_render : c->f_render_stream;
         c->last_kernel = (c->n_padded <= RT_TILE_SPHERES) ? "rt_render" : "rt_render_stream";

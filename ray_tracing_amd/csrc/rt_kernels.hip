@@ -1024,7 +1024,7 @@ RT_DEV void render_queue_body(const Scene& sc, uint32_t* __restrict__ rgba, floa
 // render_body<true> does; in every round each wavefront either traces its next 64 camera rays (scan_primary on
 // the tile's geo0 copy) or one segment of its bounce rays (scan_tile), whichever keeps its lanes busy: camera
 // rays when a lane is out of work and the queue is empty, bounce rays otherwise.
-//   LDS: [geo S float4][geo0 S float4], S = RT_TILE_SPHERES, then per wavefront as in render_queue_body.
+//   LDS: [geo S float4][geo0 S float4], S = RT_Q_STREAM_TILE, then per wavefront as in render_queue_body.
 RT_DEV void render_queue_stream_body(const Scene& sc, uint32_t* __restrict__ rgba, float4* __restrict__ linear,
                                      unsigned long long* __restrict__ segments, uint32_t* __restrict__ work,
                                      const RtCamera& cam, const RtLaunch& L) {
@@ -1034,7 +1034,7 @@ RT_DEV void render_queue_stream_body(const Scene& sc, uint32_t* __restrict__ rgb
     const uint32_t flags = L.flags;
     const uint32_t P = L.unit_w * L.unit_h;
     const uint32_t n_samp = L.max_depth > 0u ? P * L.samples_per_pixel : 0u;   // per unit
-    const uint32_t S = tile_capacity(L);
+    const uint32_t S = RT_Q_STREAM_TILE;
     const V3 T = ld3(L.translate);
 
     float4* geo = rt_lds;
@@ -1150,9 +1150,9 @@ RT_DEV void render_queue_stream_body(const Scene& sc, uint32_t* __restrict__ rgb
         Best b;
         b.t = L.t_max;
         b.idx = -1;
-        for (uint32_t first = 0u; first < L.n_padded; first += RT_TILE_SPHERES) {
+        for (uint32_t first = 0u; first < L.n_padded; first += RT_Q_STREAM_TILE) {
             uint32_t count = L.n_padded - first;
-            if (count > RT_TILE_SPHERES) count = RT_TILE_SPHERES;
+            if (count > RT_Q_STREAM_TILE) count = RT_Q_STREAM_TILE;
             if (first) __syncthreads();                          // previous tile fully scanned
             for (uint32_t i = threadIdx.x; i < count; i += blockDim.x) {
                 const float4 c = sc.geom[first + i];
@@ -1234,7 +1234,7 @@ rt_render_queue(const float4* geom, const float4* exact, const float4* shade, co
     render_queue_body(sc, rgba, linear, segments, work, cam, L);
 }
 
-extern "C" __global__ void __launch_bounds__(1024)
+extern "C" __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(5)))
 rt_render_queue_stream(const float4* geom, const float4* exact, const float4* shade, const uint32_t* mat, uint32_t* rgba,
                        float4* linear, unsigned long long* segments, uint32_t* work, RtCamera cam, RtLaunch L) {
     Scene sc = {geom, exact, shade, mat};

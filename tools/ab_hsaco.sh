@@ -2,7 +2,7 @@
 # A/B timing of code objects on ONE box (devices differ by several per cent, so both arms must run in the same
 # call): tools/ab_hsaco.sh a.hsaco b.hsaco ...   -- each is timed twice, interleaved, on the four configurations.
 set -e
-export RT_CHUNK=${RT_CHUNK:-2}
+export RT_CHUNK=${RT_CHUNK:-1}
 for round in 1 2; do
   for h in "$@"; do
     echo "== round $round $h"

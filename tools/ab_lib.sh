@@ -1,7 +1,7 @@
 #!/bin/bash
 # A/B timing of whole library builds on ONE box: tools/ab_lib.sh a.so b.so ...  (each twice, interleaved).
 set -e
-export RT_CHUNK=${RT_CHUNK:-2}
+export RT_CHUNK=${RT_CHUNK:-1}
 for round in 1 2; do
   for l in "$@"; do
     echo "== round $round $l"
