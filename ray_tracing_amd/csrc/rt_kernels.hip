@@ -808,6 +808,45 @@ RT_DEV void add_sample(unsigned long long* acc, uint32_t P, uint32_t pix, V3 col
     atomicAdd(acc + 2u * P + pix, (unsigned long long)to_fixed(color.z));
 }
 
+// Queue entry j becomes the lane's path: the ray that left the camera ray's hit, one segment done.
+RT_DEV void take_queued(const Scene& sc, const RtLaunch& L, const uint32_t* q, uint32_t j, const Slot& u0, const Slot& u1,
+                        Path& p, uint32_t& s, uint32_t& pixel, uint32_t& pixslot, float& band) {
+    const uint32_t P = L.unit_w * L.unit_h;
+    p.o = v3(__uint_as_float(q[j]), __uint_as_float(q[64u + j]), __uint_as_float(q[128u + j]));
+    p.d = v3(__uint_as_float(q[192u + j]), __uint_as_float(q[256u + j]), __uint_as_float(q[320u + j]));
+    s = q[384u + j];
+    const uint32_t meta = q[448u + j];
+    const uint32_t sphere = meta & 0xffffu, ps = meta >> 16;
+    const bool in1 = ps >= 64u;
+    const uint32_t pix = ps & 63u;
+    const uint32_t dx = pix & (L.unit_w - 1u), dy = pix >> L.unit_shift;
+    const uint32_t x = (in1 ? u1.x0 : u0.x0) + dx, y = (in1 ? u1.y0 : u0.y0) + dy;
+    pixel = y * L.width + x;
+    pixslot = pix + (in1 ? 3u * P : 0u);
+    p.seg = 1u;
+    if (L.flags & RT_FLAG_BAND_ALBEDO) {
+        band = band_of(L, x);
+        p.nb = 1u;
+    } else {
+        const float4 al = sc.shade[2u * sphere + 1u];
+        p.thr = v3(al.x, al.y, al.z);                            // 1 * albedo (ray.cu:37)
+        p.nb = 0u;
+    }
+}
+
+// Appends the lanes' scattered camera rays (`cont`) to the empty queue, packed from slot 0; returns their number.
+RT_DEV uint32_t queue_rays(uint32_t* q, bool cont, const Path& p, uint32_t s, uint32_t slot, uint32_t pix, uint32_t sphere) {
+    const unsigned long long cm = __ballot(cont);
+    if (cont) {
+        const uint32_t r = __builtin_amdgcn_mbcnt_hi((uint32_t)(cm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cm, 0u));
+        q[r] = __float_as_uint(p.o.x); q[64u + r] = __float_as_uint(p.o.y); q[128u + r] = __float_as_uint(p.o.z);
+        q[192u + r] = __float_as_uint(p.d.x); q[256u + r] = __float_as_uint(p.d.y); q[320u + r] = __float_as_uint(p.d.z);
+        q[384u + r] = s;
+        q[448u + r] = ((slot * 64u + pix) << 16) | sphere;
+    }
+    return (uint32_t)__popcll(cm);
+}
+
 // Traces and shades the camera rays of samples first .. first+63 of unit `u` (sample i: pixel i % P, sample
 // number i / P).  Called by the whole wavefront.  Finished samples (miss, depth limit, pixel outside the
 // image) are counted in `completed`; the others leave a ray in the queue, packed from slot 0 (`queued`).
@@ -851,15 +890,7 @@ RT_DEV void primary_batch(const Scene& sc, const Tile& tile, const float4* __res
             cont = true;
         }
     }
-    const unsigned long long cm = __ballot(cont);
-    if (cont) {
-        const uint32_t r = __builtin_amdgcn_mbcnt_hi((uint32_t)(cm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cm, 0u));
-        q[r] = __float_as_uint(p.o.x); q[64u + r] = __float_as_uint(p.o.y); q[128u + r] = __float_as_uint(p.o.z);
-        q[192u + r] = __float_as_uint(p.d.x); q[256u + r] = __float_as_uint(p.d.y); q[320u + r] = __float_as_uint(p.d.z);
-        q[384u + r] = s;
-        q[448u + r] = ((slot * 64u + pix) << 16) | sphere;
-    }
-    queued = (uint32_t)__popcll(cm);
+    queued = queue_rays(q, cont, p, s, slot, pix, sphere);
     completed = (uint32_t)__popcll(__ballot(done));
 }
 
@@ -948,26 +979,7 @@ RT_DEV void render_queue_body(const Scene& sc, uint32_t* __restrict__ rgba, floa
             }
             const uint32_t j = q_head + __builtin_amdgcn_mbcnt_hi((uint32_t)(want >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)want, 0u));
             if (need && j < q_count) {
-                p.o = v3(__uint_as_float(q[j]), __uint_as_float(q[64u + j]), __uint_as_float(q[128u + j]));
-                p.d = v3(__uint_as_float(q[192u + j]), __uint_as_float(q[256u + j]), __uint_as_float(q[320u + j]));
-                s = q[384u + j];
-                const uint32_t meta = q[448u + j];
-                const uint32_t sphere = meta & 0xffffu, ps = meta >> 16;
-                const bool in1 = ps >= 64u;
-                const uint32_t pix = ps & 63u;
-                const uint32_t dx = pix & (L.unit_w - 1u), dy = pix >> L.unit_shift;
-                const uint32_t x = (in1 ? u1.x0 : u0.x0) + dx, y = (in1 ? u1.y0 : u0.y0) + dy;
-                pixel = y * L.width + x;
-                pixslot = pix + (in1 ? 3u * P : 0u);
-                p.seg = 1u;
-                if (flags & RT_FLAG_BAND_ALBEDO) {
-                    band = band_of(L, x);
-                    p.nb = 1u;
-                } else {
-                    const float4 al = sc.shade[2u * sphere + 1u];
-                    p.thr = v3(al.x, al.y, al.z);                // 1 * albedo (ray.cu:37)
-                    p.nb = 0u;
-                }
+                take_queued(sc, L, q, j, u0, u1, p, s, pixel, pixslot, band);
                 need = false;
                 active = true;
             }
@@ -1075,26 +1087,7 @@ RT_DEV void render_queue_stream_body(const Scene& sc, uint32_t* __restrict__ rgb
         if (want != 0ull && q_head < q_count) {
             const uint32_t j = q_head + __builtin_amdgcn_mbcnt_hi((uint32_t)(want >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)want, 0u));
             if (need && j < q_count) {
-                p.o = v3(__uint_as_float(q[j]), __uint_as_float(q[64u + j]), __uint_as_float(q[128u + j]));
-                p.d = v3(__uint_as_float(q[192u + j]), __uint_as_float(q[256u + j]), __uint_as_float(q[320u + j]));
-                s = q[384u + j];
-                const uint32_t meta = q[448u + j];
-                const uint32_t sphere = meta & 0xffffu, ps = meta >> 16;
-                const bool in1 = ps >= 64u;
-                const uint32_t pix = ps & 63u;
-                const uint32_t dx = pix & (L.unit_w - 1u), dy = pix >> L.unit_shift;
-                const uint32_t x = (in1 ? u1.x0 : u0.x0) + dx, y = (in1 ? u1.y0 : u0.y0) + dy;
-                pixel = y * L.width + x;
-                pixslot = pix + (in1 ? 3u * P : 0u);
-                p.seg = 1u;
-                if (flags & RT_FLAG_BAND_ALBEDO) {
-                    band = band_of(L, x);
-                    p.nb = 1u;
-                } else {
-                    const float4 al = sc.shade[2u * sphere + 1u];
-                    p.thr = v3(al.x, al.y, al.z);
-                    p.nb = 0u;
-                }
+                take_queued(sc, L, q, j, u0, u1, p, s, pixel, pixslot, band);
                 need = false;
                 active = true;
             }
@@ -1182,16 +1175,8 @@ RT_DEV void render_queue_stream_body(const Scene& sc, uint32_t* __restrict__ rgb
                     cont = true;
                 }
             }
-            const unsigned long long cm = __ballot(cont);
-            if (cont) {
-                const uint32_t r = __builtin_amdgcn_mbcnt_hi((uint32_t)(cm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cm, 0u));
-                q[r] = __float_as_uint(bp.o.x); q[64u + r] = __float_as_uint(bp.o.y); q[128u + r] = __float_as_uint(bp.o.z);
-                q[192u + r] = __float_as_uint(bp.d.x); q[256u + r] = __float_as_uint(bp.d.y); q[320u + r] = __float_as_uint(bp.d.z);
-                q[384u + r] = bs;
-                q[448u + r] = ((cur * 64u + bpix) << 16) | sphere;
-            }
             q_head = 0u;
-            q_count = (uint32_t)__popcll(cm);
+            q_count = queue_rays(q, cont, bp, bs, cur, bpix, sphere);
             const uint32_t completed = (uint32_t)__popcll(__ballot(bdone));
             if (cur) u1.left -= completed; else u0.left -= completed;
             next_samp = next_samp + 64u < n_samp ? next_samp + 64u : n_samp;
