@@ -148,3 +148,24 @@ def test_p3_float_writer_has_the_reference_image_format(rt, tmp_path):
 def test_command_line_renderer_is_built():
     exe = os.path.join(ROOT, "ray_tracing_amd", "csrc", "rt_render")
     assert os.path.exists(exe) and os.access(exe, os.X_OK)
+
+
+def test_rust_crate_declares_only_exported_symbols():
+    """rust/ray_tracing_hip/src/ffi.rs (source only: no Rust toolchain here) must not drift from the C header:
+    every function it declares is exported by the library, and its three structs have the header's sizes."""
+    import re
+    import ray_tracing_amd._ffi as ffi
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "rust", "ray_tracing_hip", "src", "ffi.rs")).read()
+    names = re.findall(r"pub fn (rt_[a-z0-9_]+)\(", text)
+    assert len(names) >= 20
+    for n in names:
+        assert n in ffi.SYMBOLS, n
+    def words(struct):
+        body = re.search(r"pub struct %s \{(.*?)\n\}" % struct, text, re.S).group(1)
+        total = 0
+        for ty in re.findall(r"pub [a-z0-9_]+: ([^,]+),", body):
+            m = re.match(r"\[(f32|u32); (\d+)\]", ty)
+            total += {"f32": 4, "u32": 4, "u64": 8}[m.group(1) if m else ty] * (int(m.group(2)) if m else 1)
+        return total
+    assert words("RtSphere") == 36 and words("RtCamera") == 148 and words("RtParams") == 40
