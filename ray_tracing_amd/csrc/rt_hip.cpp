@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -55,7 +56,8 @@ struct rt_ctx {
     std::string err;
 };
 
-static std::string g_create_error;
+// message of the last failure that had no context to carry it (rt_create, rt_comm_id, ...), per calling thread
+static thread_local std::string g_create_error;
 
 namespace {
 
@@ -266,9 +268,16 @@ struct Rccl {
     std::string error;
 };
 
+void load_rccl(Rccl& r);
+
 Rccl* rccl() {
     static Rccl r;
-    if (r.handle || !r.error.empty()) return &r;
+    static std::once_flag once;
+    std::call_once(once, [] { load_rccl(r); });
+    return &r;
+}
+
+void load_rccl(Rccl& r) {
     const char* env = std::getenv("RT_RCCL_LIB");
     const char* names[] = {env, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     for (const char* n : names) {
@@ -277,7 +286,7 @@ Rccl* rccl() {
         if (!r.handle) r.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
         if (r.handle) break;
     }
-    if (!r.handle) { r.error = std::string("cannot load RCCL: ") + (dlerror() ? dlerror() : "not found"); return &r; }
+    if (!r.handle) { r.error = std::string("cannot load RCCL: ") + (dlerror() ? dlerror() : "not found"); return; }
     bool ok = true;
     auto sym = [&](const char* name) { void* p = dlsym(r.handle, name); if (!p) { ok = false; r.error = std::string("RCCL lacks ") + name; } return p; };
     r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
@@ -289,7 +298,6 @@ Rccl* rccl() {
     r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
     r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
     if (!ok) { dlclose(r.handle); r.handle = nullptr; }
-    return &r;
 }
 
 int rccl_fail(rt_ctx* c, ncclResult_t e, const char* what) {
