@@ -316,6 +316,21 @@ def test_c5_full_size(oracle, rt, hip):
     assert band["rays"] == seg and np.array_equal(band["linear"].view(np.uint32), lin.view(np.uint32))
 
 
+def test_index_width_on_a_151_megapixel_frame(oracle, rt, hip):
+    """16384 x 9216 pixels (pixel indices up to 1.5e8, a 604 MB frame): rows from the middle and the very end of
+    the frame against the checker."""
+    sp = rt.scene_book1_final(1)
+    cam = rt.Camera.look_at(16.0 / 9.0, 16384, 20.0, (13.0, 2.0, 3.0), (0.0, 0.0, 0.0))
+    assert cam.image_height == 9216
+    p = rt.DeviceGUI(samples_per_pixel=2, max_depth=8, seed=3, sample_chunk=1)
+    hip.upload_scene(sp)
+    got = hip.render(cam, p)
+    ocam = oracle.camera_f32_from_rt(cam.block)
+    for row0, rows in ((5000, 2), (9213, 3)):
+        rgba, _, _ = oracle.render(ocam, sp, p, row0=row0, rows=rows)
+        assert np.array_equal(got["rgba"][row0:row0 + rows], rgba)
+
+
 def test_unit_size_does_not_change_the_image(rt, hip, monkeypatch):
     """The shape of the pixel units the wavefronts take is a scheduling choice: exact accumulation makes the
     frame identical for all of them."""
