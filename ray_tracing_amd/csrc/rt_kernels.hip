@@ -93,9 +93,11 @@ RT_DEV V3 random_unit_vector(Rng& g, Stats& st) {
     for (int i = 0; i < 20 && !done; i++) {
         st.add(5, 1u);
         st.wave(7);
-        float x = fmaf(2.0f, rand01(g), -1.0f);
-        float y = fmaf(2.0f, rand01(g), -1.0f);
-        float z = fmaf(2.0f, rand01(g), -1.0f);
+        // 2 * rand01 - 1 in one rounding, as the checker's fmaf(2, rand01, -1): k * 2^-24 is exact, so both are
+        // the single rounding of k * 2^-23 - 1
+        float x = fmaf((float)(pcg_next(g) >> 8), 0x1p-23f, -1.0f);
+        float y = fmaf((float)(pcg_next(g) >> 8), 0x1p-23f, -1.0f);
+        float z = fmaf((float)(pcg_next(g) >> 8), 0x1p-23f, -1.0f);
         V3 q = v3(x, y, z);
         if (vdot(q, q) <= 1.0f) { p = q; done = true; }
     }
