@@ -1,6 +1,11 @@
-// rt_kernels.hip -- gfx950 code object of the path tracer: one work-item per pixel, the sphere list
-// streamed from LDS (every lane of a wavefront reads the same float4 per step), counter-based PCG32
-// streams, fp32 register accumulation, gamma + RGBA8 store.  Built with
+// rt_kernels.hip -- gfx950 code object of the path tracer: the sphere list streamed from LDS (every lane
+// of a wavefront reads the same float4 per step), counter-based PCG32 streams, fp32 register
+// accumulation, gamma + RGBA8 store.  Four render kernels share the code below:
+//   rt_render_queue         every sample its own work item, scene within one LDS tile (the fast path)
+//   rt_render_queue_stream  the same for longer sphere lists, streamed tile by tile
+//   rt_render               work items of `chunk` samples, or one lane per pixel in the reference's fold order
+//   rt_render_stream        the same for longer sphere lists
+// Built with
 //   hipcc --offload-arch=gfx950 --genco -O3 -ffp-contract=off
 // and loaded with hipModuleLoadData by rt_hip.cpp.  No MFMA: the work is divergent scalar fp32.
 //
@@ -135,11 +140,11 @@ RT_DEV void sphere_terms(float cx, float cy, float cz, float rr, V3 o, V3 d, flo
 
 // LDS sphere tile of one workgroup:
 //   geo[i] = {cx - Tx, cy - Ty, cz - Tz, m}   scan filter only (T, m: see scan_tile)
-//   exa[i] = {cx, cy, cz, r*r}                exact test
+//   exa[i] = {cx, cy, cz, r*r}                exact test (LDS, or global memory in the queue kernels)
 struct Tile { const float4* geo; const float4* exa; };
 
 // Per-lane list of candidate spheres of the tile being scanned, kept in LDS as a column of a
-// [RT_CAND_CAP][64] u16 array per wavefront (lane l owns column l, so pushes never conflict).
+// [cap][64] u16 array per wavefront (lane l owns column l, so pushes never conflict).
 struct Cand { uint16_t* col; uint32_t n; uint32_t cap; };   // cap: slots per lane (wave-uniform)
 
 RT_DEV void push(Cand& c, uint32_t idx) {
