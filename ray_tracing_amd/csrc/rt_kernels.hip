@@ -1163,6 +1163,9 @@ RT_DEV void render_queue_stream_body(const Scene& sc, uint32_t* __restrict__ rgb
             const Tile tile = {geo, sc.exact + first};           // exact-test data from global memory
             if (scanning) {
                 if (primary) scan_primary(geo0, tile, count, (int)first, T, ro, rd, ra, L.t_min, b, cand, st);
+#ifdef RT_EXP_PRIMARY2
+                if (primary) scan_primary(geo0, tile, count, (int)first, T, ro, rd, ra, L.t_min, b, cand, st);   // cost experiment
+#endif
                 else scan_tile(tile, count, (int)first, T, ro, rd, ra, L.t_min, b, cand, st);
             }
         }
