@@ -94,7 +94,10 @@ int rt_comm_init(rt_ctx *ctx, const uint8_t id[RT_COMM_ID_BYTES], uint32_t world
  * tiles r, r+world, ...; the tile buffers travel to rank 0 (grouped ncclSend/ncclRecv on the context's
  * stream), a copy kernel puts them in image order, and rank 0's frame_out (H*W*4 bytes, host) gets the RGBA8
  * frame -- bit-identical to rt_render_rows on one GPU.  frame_out is ignored on the other ranks.  rays_out
- * (may be NULL) receives this rank's own segment count.  A context without rt_comm_init is rank 0 of 1. */
+ * (may be NULL) receives this rank's own segment count.  A context without rt_comm_init is rank 0 of 1.
+ * Before any tile travels the ranks exchange one status word (4-byte all-reduce): if a rank failed locally
+ * (allocation, launch), it returns its own error and every other rank returns RT_ERR_COMM instead of waiting
+ * for it.  Arguments must be the same on all ranks. */
 int rt_render_frame_sharded(rt_ctx *ctx, const RtCamera *cam, const RtParams *params, uint32_t tile_rows,
                             uint8_t *frame_out, uint64_t *rays_out);
 /* The copy kernel of the gather by itself, for hosts that move the tile buffers with a transport of their own
@@ -115,7 +118,8 @@ int rt_show_random(rt_ctx *ctx, uint32_t width, uint32_t height, uint64_t seed, 
 
 /* Milliseconds the last render kernel took on the GPU (hipEvent pair around the launch). */
 float rt_last_kernel_ms(const rt_ctx *ctx);
-/* Name of the kernel the last render launched (rt_render, rt_render_queue or rt_render_stream), for profiles. */
+/* Name of the kernel the last render launched (rt_render, rt_render_stream, rt_render_queue or
+ * rt_render_queue_stream), for profiles. */
 const char *rt_last_kernel_name(const rt_ctx *ctx);
 
 /* Diagnostic: the 16 64-bit counters of the last render that asked for rays_out.  out[0] = ray segments;
@@ -125,6 +129,13 @@ const char *rt_last_kernel_name(const rt_ctx *ctx);
  * (scan filter, decode, exact tests, hit + scatter, sky / next sample, hand-out, rest).  No counterpart in the
  * reference. */
 int rt_debug_counters(rt_ctx *ctx, uint64_t out[16]);
+
+/* Diagnostic: scheduling experiments on this context.  unit_w x unit_h (powers of two, at most 64 pixels;
+ * 0, 0 = the library's choice) forces the shape of the pixel units the wavefronts take when sample_chunk > 0;
+ * no_queue != 0 keeps sample_chunk = 1 on the work-item kernel instead of the camera-ray-batch kernel.  Neither
+ * changes a single bit of the image (exact accumulation), only the timing.  No counterpart in the reference
+ * beyond its block_dim slider (gui.rs:287). */
+int rt_debug_schedule(rt_ctx *ctx, uint32_t unit_w, uint32_t unit_h, int no_queue);
 
 /* Name and compute-unit count of the context's GPU. */
 int rt_device_info(const rt_ctx *ctx, char *name, size_t name_size, int *compute_units, int *clock_khz);

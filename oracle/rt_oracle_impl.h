@@ -260,7 +260,8 @@ static inline int64_t NAME(to_fixed)(REAL x) {
 #else
     REAL hi = floor(x);
 #endif
-    REAL frac = x - hi; /* exact, in [0,1) */
+    REAL frac = x - hi; /* in [0,1], exact unless x is a tiny negative number: then hi = -1 and x + 1 rounds to 1 */
+    if (frac >= R(1.0)) { hi += R(1.0); frac = R(0.0); }
     uint32_t lo = (uint32_t)(frac * R(4294967296.0)); /* truncation */
     return (int64_t)((uint64_t)(int64_t)(int32_t)hi << 32) + (int64_t)lo;
 }

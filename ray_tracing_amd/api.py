@@ -298,6 +298,12 @@ class HipWorld:
         self._check(self._lib.rt_debug_counters(self._ctx, C.byref(out)))
         return list(out)
 
+    def debug_schedule(self, unit=None, no_queue=False):
+        """Scheduling experiments: unit = (w, h) forces the pixel-unit shape (None: the library's choice);
+        no_queue keeps sample_chunk = 1 on the work-item kernel.  The image does not change."""
+        w, h = unit if unit else (0, 0)
+        self._check(self._lib.rt_debug_schedule(self._ctx, w, h, int(bool(no_queue))))
+
     def device_info(self):
         name = C.create_string_buffer(600)
         cus, khz = C.c_int(0), C.c_int(0)

@@ -35,6 +35,15 @@ typedef struct RtLaunch {
     float    translate[3];     // T of the scan filter: component-wise median of the sphere centres
 } RtLaunch;
 
+// Launch-wide counter block of the render kernels, device memory, cleared before every launch: sixteen 64-bit
+// words; [0] path segments traced, [1..7] and [9..15] diagnostics of -DRT_STATS builds, byte 64: the 32-bit
+// counter the wavefronts take pixel units from.
+// The code object states the size it was built with in its global word `rt_counter_bytes`; the launcher sizes
+// (or, for the static scratch array, checks) the block by that word.
+#ifndef RT_COUNTER_BYTES
+#define RT_COUNTER_BYTES 128
+#endif
+
 // spheres per unrolled scan step (8 measured best: 4 is 3 % slower, 16 costs a wave of occupancy and 2 %)
 #define RT_SCAN_UNROLL 8u
 // Spheres staged in LDS at a time: 1024 x 32 B = 32 KiB.  Scenes up to this size are staged once per

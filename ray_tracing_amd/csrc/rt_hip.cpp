@@ -43,14 +43,20 @@ struct rt_ctx {
     uint32_t n_spheres = 0, n_padded = 0;
     bool have_scene = false;
     void *d_rgba = nullptr, *d_linear = nullptr, *d_hits = nullptr, *d_counter = nullptr;
+    size_t counter_need = RT_COUNTER_BYTES, cap_counter = 0;   // counter block the loaded code object asks for; bytes d_counter holds
+    // scheduling experiments (rt_debug_schedule): forced unit shape (0 = the library's choice), item kernel for sample_chunk 1
+    uint32_t dbg_unit_w = 0, dbg_unit_h = 0;
+    bool dbg_no_queue = false;
     size_t cap_rgba = 0, cap_linear = 0, cap_hits = 0;
     // multi-GPU gather: this context is rank `rank` of `world`
     ncclComm_t comm = nullptr;
     uint32_t world = 1, rank = 0;
+    void* d_status = nullptr;                        // two 32-bit words for the ranks' status exchange (rt_comm_init)
     void *d_tiles = nullptr, *d_frame = nullptr;     // rank's tile buffer (rank 0: all ranks' buffers), assembled frame
     size_t cap_tiles = 0, cap_frame = 0;
     float last_ms = 0.0f;
     const char* last_kernel = "";
+    void* last_counters = nullptr;      // counter block of the last render launch
     int compute_units = 0, clock_khz = 0;
     char name[600] = {0};
     std::string err;
@@ -67,6 +73,10 @@ int fail(rt_ctx* c, int code, const std::string& msg) {
 }
 
 int hip_fail(rt_ctx* c, hipError_t e, const char* what) {
+    // The runtime also keeps the error as this thread's "last error"; the code is reported to the caller here, so
+    // it is cleared there: other users of the runtime in this process (PyTorch checks hipGetLastError after its
+    // own launches) must not find it later and take it for theirs.
+    (void)hipGetLastError();
     std::string m = std::string(what) + ": " + hipGetErrorName(e) + " (" + hipGetErrorString(e) + ")";
     return fail(c, (int)e, m);
 }
@@ -100,6 +110,35 @@ int load_image(rt_ctx* c, const void* image) {
         (void)hipModuleUnload(m);
         return hip_fail(c, e, "hipModuleGetFunction");
     }
+    // the counter block this object's kernels expect (objects without the word: the layout of rt_device.h)
+    size_t need = RT_COUNTER_BYTES;
+    {
+        hipDeviceptr_t sym = nullptr;
+        size_t sym_bytes = 0;
+        uint32_t word = 0;
+        if (hipModuleGetGlobal(&sym, &sym_bytes, m, "rt_counter_bytes") == hipSuccess && sym && sym_bytes == sizeof word) {
+            if ((e = hipMemcpy(&word, sym, sizeof word, hipMemcpyDeviceToHost)) != hipSuccess) {
+                (void)hipModuleUnload(m);
+                return hip_fail(c, e, "hipMemcpy(rt_counter_bytes)");
+            }
+            if (word < RT_COUNTER_BYTES || word > (1u << 20) || word % 8u != 0u) {
+                (void)hipModuleUnload(m);
+                return fail(c, RT_ERR_INVALID, "code object states an implausible counter block size");
+            }
+            need = word;
+        } else {
+            (void)hipGetLastError();
+        }
+    }
+    if (need > c->cap_counter) {
+        void* fresh = nullptr;
+        if ((e = hipMalloc(&fresh, need)) != hipSuccess) { (void)hipModuleUnload(m); return hip_fail(c, e, "hipMalloc(counter block)"); }
+        if (c->d_counter) (void)hipFree(c->d_counter);
+        if (c->last_counters == c->d_counter) c->last_counters = nullptr;
+        c->d_counter = fresh;
+        c->cap_counter = need;
+    }
+    c->counter_need = need;
     if (c->module) (void)hipModuleUnload(c->module);
     c->module = m;
     c->f_render = fr; c->f_render_queue = fq; c->f_render_queue_stream = fqs; c->f_render_stream = fs; c->f_hits = fh; c->f_random = fx; c->f_assemble = fa;
@@ -170,12 +209,7 @@ RtLaunch make_launch(const rt_ctx* c, const RtCamera* cam, const RtParams* p, ui
         while (L.unit_w * L.unit_h < 64u && (uint64_t)L.unit_w * L.unit_h * L.n_chunks < 64u * 8u) {   // too few items per lane
             if (L.unit_h < L.unit_w && height_ok(2u * L.unit_h)) L.unit_h *= 2u; else L.unit_w *= 2u;
         }
-        const char* env = std::getenv("RT_UNIT");                       // "WxH", for experiments
-        if (env) {
-            unsigned w = 0, h = 0;
-            auto pow2 = [](unsigned v) { return v && !(v & (v - 1u)); };
-            if (std::sscanf(env, "%ux%u", &w, &h) == 2 && pow2(w) && pow2(h) && w * h <= 64u && height_ok(h)) { L.unit_w = w; L.unit_h = h; }
-        }
+        if (c->dbg_unit_w && height_ok(c->dbg_unit_h)) { L.unit_w = c->dbg_unit_w; L.unit_h = c->dbg_unit_h; }   // rt_debug_schedule
     }
     for (int k = 0; k < 3; k++) L.translate[k] = c->translate[k];
     for (L.unit_shift = 0; (1u << L.unit_shift) < L.unit_w; L.unit_shift++) {}
@@ -199,15 +233,16 @@ size_t lds_bytes(const rt_ctx* c, unsigned block, unsigned unit_pixels) {
 }
 
 // One render launch into device buffers; blocking; fills last_ms and (optionally) the segment count.
+// `counters`: RT_COUNTER_BYTES of device memory for the launch-wide counters.
 int launch_render(rt_ctx* c, const RtCamera* cam, const RtParams* p, RtLaunch L, void* d_rgba, void* d_linear,
-                  uint64_t* rays_out) {
+                  uint64_t* rays_out, void* counters) {
     unsigned grid, block;
     launch_geometry(p, L.n_units, &grid, &block);
     const unsigned waves = block / 64u, P = L.unit_w * L.unit_h;
     hipFunction_t f;
     unsigned lds;
-    const char* mode = std::getenv("RT_NO_QUEUE");           // experiments: keep sample_chunk = 1 on the item kernel
-    if (L.n_chunks > 1 && L.chunk == 1 && !(mode && *mode == '1') && (uint64_t)P * L.samples_per_pixel < (1ull << 31) &&
+    if ((uint64_t)P * L.n_chunks >= (1ull << 31)) return fail(c, RT_ERR_INVALID, "too many work items per pixel unit (samples_per_pixel / sample_chunk too large)");
+    if (L.n_chunks > 1 && L.chunk == 1 && !c->dbg_no_queue && (uint64_t)P * L.samples_per_pixel < (1ull << 31) &&
         c->n_padded <= 65536u) {                                 // a queued ray names the sphere it left in 16 bits
         // every sample its own item: camera rays traced in batches, bounce rays from a queue
         const bool one_tile = c->n_padded <= RT_TILE_SPHERES;
@@ -227,9 +262,9 @@ int launch_render(rt_ctx* c, const RtCamera* cam, const RtParams* p, RtLaunch L,
     const unsigned fill = (unsigned)resident * (unsigned)(c->compute_units > 0 ? c->compute_units : 1);
     if (grid > fill) grid = fill;
     // counter block: [0] path segments (+ diagnostics in [1..7]), 64-bit each; byte 64: the unit counter
-    void* d_count = rays_out ? c->d_counter : nullptr;
-    void* d_work = static_cast<char*>(c->d_counter) + 64;
-    RT_HIP(c, hipMemsetAsync(c->d_counter, 0, 128, c->stream));
+    void* d_count = rays_out ? counters : nullptr;
+    void* d_work = static_cast<char*>(counters) + 64;
+    RT_HIP(c, hipMemsetAsync(counters, 0, c->counter_need, c->stream));
     RtCamera cam_copy = *cam;
     void* args[] = {&c->d_geom, &c->d_exact, &c->d_shade, &c->d_mat, &d_rgba, &d_linear, &d_count, &d_work, &cam_copy, &L};
     RT_HIP(c, hipEventRecord(c->ev0, c->stream));
@@ -238,7 +273,8 @@ int launch_render(rt_ctx* c, const RtCamera* cam, const RtParams* p, RtLaunch L,
     RT_HIP(c, hipEventRecord(c->ev1, c->stream));
     RT_HIP(c, hipStreamSynchronize(c->stream));
     RT_HIP(c, hipEventElapsedTime(&c->last_ms, c->ev0, c->ev1));
-    if (rays_out) RT_HIP(c, hipMemcpy(rays_out, c->d_counter, 8, hipMemcpyDeviceToHost));
+    if (rays_out) RT_HIP(c, hipMemcpy(rays_out, counters, 8, hipMemcpyDeviceToHost));
+    c->last_counters = counters;
     return 0;
 }
 
@@ -264,6 +300,7 @@ struct Rccl {
     decltype(&ncclRecv) Recv = nullptr;
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
     std::string error;
 };
@@ -279,14 +316,19 @@ Rccl* rccl() {
 
 void load_rccl(Rccl& r) {
     const char* env = std::getenv("RT_RCCL_LIB");
-    const char* names[] = {env, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    const char* defaults[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    std::vector<const char*> names;
+    if (env && *env) names.push_back(env);                 // an explicit name is the only one tried
+    else names.assign(std::begin(defaults), std::end(defaults));
+    std::string why;
     for (const char* n : names) {
-        if (!n || !*n) continue;
         r.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
         if (!r.handle) r.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
         if (r.handle) break;
+        const char* e = dlerror();                         // one call: it returns the message and clears it
+        if (why.empty()) why = e ? e : "not found";
     }
-    if (!r.handle) { r.error = std::string("cannot load RCCL: ") + (dlerror() ? dlerror() : "not found"); return; }
+    if (!r.handle) { r.error = "cannot load RCCL: " + (why.empty() ? std::string("not found") : why); return; }
     bool ok = true;
     auto sym = [&](const char* name) { void* p = dlsym(r.handle, name); if (!p) { ok = false; r.error = std::string("RCCL lacks ") + name; } return p; };
     r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
@@ -296,6 +338,7 @@ void load_rccl(Rccl& r) {
     r.Recv = reinterpret_cast<decltype(r.Recv)>(sym("ncclRecv"));
     r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(sym("ncclGroupStart"));
     r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
+    r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(sym("ncclAllReduce"));
     r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
     if (!ok) { dlclose(r.handle); r.handle = nullptr; }
 }
@@ -361,7 +404,6 @@ int rt_create(int device, rt_ctx** out) {
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail(hip_fail(c, e, "hipStreamCreate"));
     if ((e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess)
         return bail(hip_fail(c, e, "hipEventCreate"));
-    if ((e = hipMalloc(&c->d_counter, 128)) != hipSuccess) return bail(hip_fail(c, e, "hipMalloc"));
     if ((rc = load_image(c, rt_embedded_hsaco)) != 0) return bail(rc);
     *out = c;
     return 0;
@@ -372,7 +414,7 @@ void rt_destroy(rt_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->comm && rccl()->CommDestroy) (void)rccl()->CommDestroy(c->comm);
-    void* bufs[] = {c->d_geom, c->d_exact, c->d_shade, c->d_mat, c->d_rgba, c->d_linear, c->d_hits, c->d_counter, c->d_tiles, c->d_frame};
+    void* bufs[] = {c->d_geom, c->d_exact, c->d_shade, c->d_mat, c->d_rgba, c->d_linear, c->d_hits, c->d_counter, c->d_tiles, c->d_frame, c->d_status};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -475,11 +517,26 @@ int rt_render_rows(rt_ctx* c, const RtCamera* cam, const RtParams* p, uint32_t r
     if ((rc = ensure(c, &c->d_rgba, &c->cap_rgba, px * 4))) return rc;
     if (linear_out && (rc = ensure(c, &c->d_linear, &c->cap_linear, px * 16))) return rc;
     RtLaunch L = make_launch(c, cam, p, row0, rows, rows, rows);
-    if ((rc = launch_render(c, cam, p, L, c->d_rgba, linear_out ? c->d_linear : nullptr, rays_out))) return rc;
+    if ((rc = launch_render(c, cam, p, L, c->d_rgba, linear_out ? c->d_linear : nullptr, rays_out, c->d_counter))) return rc;
     RT_HIP(c, hipMemcpy(rgba_out, c->d_rgba, px * 4, hipMemcpyDeviceToHost));      // memcpy_dtoh, ray_tracing.rs:206-208
     if (linear_out) RT_HIP(c, hipMemcpy(linear_out, c->d_linear, px * 16, hipMemcpyDeviceToHost));
     if (hit_out) return rt_primary_hits(c, cam, p, row0, rows, hit_out);
     return 0;
+}
+
+static int render_tiles_into(rt_ctx* c, const RtCamera* cam, const RtParams* p, uint32_t tile_rows, uint32_t first_tile,
+                             uint32_t tile_stride, uint32_t n_tiles, void* d_rgba, void* d_linear, uint64_t* rays_out,
+                             void* counters) {
+    if (!d_rgba) return fail(c, RT_ERR_INVALID, "d_rgba is NULL");
+    if (tile_rows == 0 || tile_rows % 8u != 0) return fail(c, RT_ERR_INVALID, "tile_rows must be a positive multiple of 8");
+    if (tile_stride == 0) return fail(c, RT_ERR_INVALID, "tile_stride must be >= 1");
+    if ((uint64_t)n_tiles * tile_rows >= (1ull << 31)) return fail(c, RT_ERR_INVALID, "too many tile rows");
+    if (n_tiles && (uint64_t)first_tile * tile_rows >= cam->image_height) return fail(c, RT_ERR_INVALID, "first_tile lies below the image");
+    if ((uint64_t)tile_stride * tile_rows >= (1ull << 31)) return fail(c, RT_ERR_INVALID, "tile_stride * tile_rows must be below 2^31");
+    RT_HIP(c, hipSetDevice(c->device));
+    if (n_tiles == 0) { if (rays_out) *rays_out = 0; c->last_ms = 0.0f; return 0; }
+    RtLaunch L = make_launch(c, cam, p, first_tile * tile_rows, n_tiles * tile_rows, tile_rows, tile_stride * tile_rows);
+    return launch_render(c, cam, p, L, d_rgba, d_linear, rays_out, counters);
 }
 
 int rt_render_tiles_device(rt_ctx* c, const RtCamera* cam, const RtParams* p, uint32_t tile_rows,
@@ -488,14 +545,7 @@ int rt_render_tiles_device(rt_ctx* c, const RtCamera* cam, const RtParams* p, ui
     int rc = check_common(c, cam, p);
     if (rc) return rc;
     if ((rc = check_render(c, p))) return rc;
-    if (!d_rgba) return fail(c, RT_ERR_INVALID, "d_rgba is NULL");
-    if (tile_rows == 0 || tile_rows % 8u != 0) return fail(c, RT_ERR_INVALID, "tile_rows must be a positive multiple of 8");
-    if (tile_stride == 0) return fail(c, RT_ERR_INVALID, "tile_stride must be >= 1");
-    if ((uint64_t)n_tiles * tile_rows >= (1ull << 31)) return fail(c, RT_ERR_INVALID, "too many tile rows");
-    RT_HIP(c, hipSetDevice(c->device));
-    if (n_tiles == 0) { if (rays_out) *rays_out = 0; c->last_ms = 0.0f; return 0; }
-    RtLaunch L = make_launch(c, cam, p, first_tile * tile_rows, n_tiles * tile_rows, tile_rows, tile_stride * tile_rows);
-    return launch_render(c, cam, p, L, d_rgba, d_linear, rays_out);
+    return render_tiles_into(c, cam, p, tile_rows, first_tile, tile_stride, n_tiles, d_rgba, d_linear, rays_out, c->d_counter);
 }
 
 int rt_primary_hits(rt_ctx* c, const RtCamera* cam, const RtParams* p, uint32_t row0, uint32_t rows, int32_t* hit_out) {
@@ -537,7 +587,7 @@ const char* rt_last_kernel_name(const rt_ctx* c) { return c ? c->last_kernel : "
 int rt_debug_counters(rt_ctx* c, uint64_t out[16]) {
     if (!c || !out) return RT_ERR_INVALID;
     RT_HIP(c, hipSetDevice(c->device));
-    RT_HIP(c, hipMemcpy(out, c->d_counter, 128, hipMemcpyDeviceToHost));
+    RT_HIP(c, hipMemcpy(out, c->last_counters ? c->last_counters : c->d_counter, RT_COUNTER_BYTES, hipMemcpyDeviceToHost));
     return 0;
 }
 
@@ -569,6 +619,7 @@ int rt_comm_init(rt_ctx* c, const uint8_t id[RT_COMM_ID_BYTES], uint32_t world, 
     RT_HIP(c, hipSetDevice(c->device));
     ncclUniqueId u;
     std::memcpy(&u, id, sizeof u);
+    if (!c->d_status) RT_HIP(c, hipMalloc(&c->d_status, 8));
     RT_RCCL(c, r->CommInitRank(&c->comm, (int)world, u, (int)rank));
     c->world = world;
     c->rank = rank;
@@ -592,43 +643,91 @@ int rt_assemble_tiles(rt_ctx* c, const void* d_gathered, uint32_t width, uint32_
 
 int rt_render_frame_sharded(rt_ctx* c, const RtCamera* cam, const RtParams* p, uint32_t tile_rows,
                             uint8_t* frame_out, uint64_t* rays_out) {
+    // Argument errors are the same on every rank (same camera and parameters by contract), so returning early
+    // on them leaves no peer waiting.  Everything that can fail on one rank only (allocation, launch) happens
+    // before the ranks exchange a status word; the tile buffers travel only if every rank is ready.
     int rc = check_common(c, cam, p);
     if (rc) return rc;
     if ((rc = check_render(c, p))) return rc;
     if (tile_rows == 0 || tile_rows % 8u != 0) return fail(c, RT_ERR_INVALID, "tile_rows must be a positive multiple of 8");
-    if (c->rank == 0 && !frame_out) return fail(c, RT_ERR_INVALID, "frame_out is NULL on rank 0");
     if (c->world > 1 && !c->comm) return fail(c, RT_ERR_INVALID, "rt_comm_init has not been called");
-    RT_HIP(c, hipSetDevice(c->device));
     const uint32_t W = cam->image_width, H = cam->image_height, world = c->world, rank = c->rank;
     const uint32_t rows_per_rank = tiles_of_rank(H, tile_rows, 0, world) * tile_rows;   // rank 0 owns the most tiles
     const size_t part = (size_t)rows_per_rank * W * 4;                                  // bytes every rank contributes
-    // rank 0 keeps all ranks' buffers side by side and renders into the first; the others hold their own only
-    if ((rc = ensure(c, &c->d_tiles, &c->cap_tiles, rank == 0 ? part * world : part))) return rc;
-    const uint32_t mine = tiles_of_rank(H, tile_rows, rank, world);
+    const size_t frame_bytes = (size_t)W * H * 4;
     uint64_t rays = 0;
-    if (mine) {
-        RtLaunch L = make_launch(c, cam, p, rank * tile_rows, mine * tile_rows, tile_rows, world * tile_rows);
-        if ((rc = launch_render(c, cam, p, L, c->d_tiles, nullptr, &rays))) return rc;
+    auto local_part = [&]() -> int {
+        if (rank == 0 && !frame_out) return fail(c, RT_ERR_INVALID, "frame_out is NULL on rank 0");
+        RT_HIP(c, hipSetDevice(c->device));
+        // rank 0 keeps all ranks' buffers side by side and renders into the first; the others hold their own only
+        int r = ensure(c, &c->d_tiles, &c->cap_tiles, rank == 0 ? part * world : part);
+        if (r) return r;
+        if (rank == 0 && (r = ensure(c, &c->d_frame, &c->cap_frame, frame_bytes))) return r;
+        const uint32_t mine = tiles_of_rank(H, tile_rows, rank, world);
+        if (mine) {
+            RtLaunch L = make_launch(c, cam, p, rank * tile_rows, mine * tile_rows, tile_rows, world * tile_rows);
+            if ((r = launch_render(c, cam, p, L, c->d_tiles, nullptr, &rays, c->d_counter))) return r;
+        }
+        return 0;
+    };
+    const int local_rc = local_part();
+    const std::string local_err = c->err;
+    if (c->comm) {
+        // one 4-byte all-reduce (max) of the ranks' status: a rank that failed above still takes part, so nobody
+        // blocks in the exchange below waiting for a peer that has already returned
+        Rccl* r = rccl();
+        const int32_t mine_failed = local_rc ? 1 : 0;
+        int32_t any_failed = 1;
+        hipError_t e = hipMemcpyAsync(c->d_status, &mine_failed, 4, hipMemcpyHostToDevice, c->stream);
+        if (e != hipSuccess) return hip_fail(c, e, "hipMemcpyAsync(status)");
+        RT_RCCL(c, r->AllReduce(c->d_status, static_cast<char*>(c->d_status) + 4, 1, ncclInt32, ncclMax, c->comm, c->stream));
+        if ((e = hipMemcpyAsync(&any_failed, static_cast<char*>(c->d_status) + 4, 4, hipMemcpyDeviceToHost, c->stream)) != hipSuccess ||
+            (e = hipStreamSynchronize(c->stream)) != hipSuccess)
+            return hip_fail(c, e, "status exchange");
+        if (local_rc) return fail(c, local_rc, local_err);
+        if (any_failed) return fail(c, RT_ERR_COMM, "rt_render_frame_sharded: another rank failed before the exchange; no tiles were sent");
+    } else if (local_rc) {
+        return local_rc;
     }
     if (rays_out) *rays_out = rays;
     if (world > 1) {
+        // the group is closed on every path, also after a failed send or receive
         Rccl* r = rccl();
-        RT_RCCL(c, r->GroupStart());
-        if (rank == 0) {
-            for (uint32_t peer = 1; peer < world; peer++)
-                RT_RCCL(c, r->Recv(static_cast<char*>(c->d_tiles) + part * peer, part, ncclUint8, (int)peer, c->comm, c->stream));
-        } else {
-            RT_RCCL(c, r->Send(c->d_tiles, part, ncclUint8, 0, c->comm, c->stream));
+        ncclResult_t first = r->GroupStart();
+        const char* what = "ncclGroupStart";
+        if (first == ncclSuccess) {
+            if (rank == 0) {
+                for (uint32_t peer = 1; peer < world && first == ncclSuccess; peer++) {
+                    first = r->Recv(static_cast<char*>(c->d_tiles) + part * peer, part, ncclUint8, (int)peer, c->comm, c->stream);
+                    what = "ncclRecv";
+                }
+            } else {
+                first = r->Send(c->d_tiles, part, ncclUint8, 0, c->comm, c->stream);
+                what = "ncclSend";
+            }
+            const ncclResult_t end = r->GroupEnd();
+            if (first == ncclSuccess && end != ncclSuccess) { first = end; what = "ncclGroupEnd"; }
         }
-        RT_RCCL(c, r->GroupEnd());
+        if (first != ncclSuccess) return rccl_fail(c, first, what);
     }
     if (rank == 0) {
-        const size_t frame_bytes = (size_t)W * H * 4;
-        if ((rc = ensure(c, &c->d_frame, &c->cap_frame, frame_bytes))) return rc;
         if ((rc = launch_assemble(c, c->d_tiles, c->d_frame, W, H, tile_rows, world, rows_per_rank))) return rc;
         RT_HIP(c, hipMemcpyAsync(frame_out, c->d_frame, frame_bytes, hipMemcpyDeviceToHost, c->stream));
     }
     RT_HIP(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int rt_debug_schedule(rt_ctx* c, uint32_t unit_w, uint32_t unit_h, int no_queue) {
+    if (!c) return RT_ERR_INVALID;
+    auto pow2 = [](uint32_t v) { return v && !(v & (v - 1u)); };
+    if (unit_w || unit_h) {
+        if (!pow2(unit_w) || !pow2(unit_h) || unit_w * unit_h > 64u)
+            return fail(c, RT_ERR_INVALID, "rt_debug_schedule: unit sides must be powers of two with at most 64 pixels per unit");
+    }
+    c->dbg_unit_w = unit_w;
+    c->dbg_unit_h = unit_h;
+    c->dbg_no_queue = no_queue != 0;
     return 0;
 }
 

@@ -258,12 +258,17 @@ int rt_write_ppm_p3f(const char* path, const float* linear, uint32_t width, uint
     FILE* f = std::fopen(path, "w");
     if (!f) return RT_ERR_IO;
     std::fprintf(f, "P3\n%u %u\n255\n", width, height);
-    char buf[3 * 32 + 4];
+    // Rust's `{}` prints an f64 with the shortest digits that round-trip and never with an exponent
+    // (2.55999e-05 is written 0.0000255999), "NaN" for a NaN and "inf" / "-inf": fixed notation here too.
+    // The largest double takes 309 digits.
+    constexpr size_t kMax = 330;
+    char buf[3 * kMax + 4];
     for (size_t k = 0; k < (size_t)width * height; k++) {
         char* q = buf;
         for (int c = 0; c < 3; c++) {
             double v = 255.999 * (double)linear[4 * k + c];
-            q = std::to_chars(q, q + 32, v).ptr;       // shortest round-trip digits, as Rust's `{}` prints an f64
+            if (v != v) { std::memcpy(q, "NaN", 3); q += 3; }
+            else q = std::to_chars(q, q + kMax, v, std::chars_format::fixed).ptr;
             *q++ = c < 2 ? ' ' : '\n';
         }
         if (std::fwrite(buf, 1, (size_t)(q - buf), f) != (size_t)(q - buf)) { std::fclose(f); return RT_ERR_IO; }

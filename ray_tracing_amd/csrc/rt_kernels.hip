@@ -19,6 +19,9 @@
 
 #define RT_DEV __device__ __forceinline__
 
+// size of the launch-wide counter block these kernels were built for (read by the launcher when the object is loaded)
+extern "C" __device__ __attribute__((used)) const uint32_t rt_counter_bytes = RT_COUNTER_BYTES;
+
 struct V3 { float x, y, z; };
 RT_DEV V3 v3(float x, float y, float z) { V3 v; v.x = x; v.y = y; v.z = z; return v; }
 RT_DEV V3 vsub(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
@@ -475,7 +478,8 @@ RT_DEV Cand cand_list(const RtLaunch& L) {
 RT_DEV long long to_fixed(float x) {
     if (!(fabsf(x) < 1073741824.0f)) return 0ll;
     float hi = floorf(x);
-    float frac = x - hi;                                         // exact, in [0,1)
+    float frac = x - hi;                                         // in [0,1], exact unless x is a tiny negative number:
+    if (frac >= 1.0f) { hi += 1.0f; frac = 0.0f; }               // then hi = -1 and x + 1 rounds to 1
     uint32_t lo = (uint32_t)(frac * 4294967296.0f);              // truncation
     return (long long)(int)hi * 4294967296ll + (long long)lo;
 }

@@ -145,6 +145,51 @@ def test_p3_float_writer_has_the_reference_image_format(rt, tmp_path):
     assert lines[8].split()[0] == repr(255.999 * float(np.float32(0.1)))
 
 
+def test_p3_float_writer_never_prints_an_exponent(rt, tmp_path):
+    """Rust's `{}` of an f64 (what wrote cpu-implementation/image.ppm) has no scientific notation: a dark pixel
+    such as 255.999 * 1e-7 is written 0.0000255999..., not 2.55999e-05; whole numbers have no fraction; a NaN
+    is `NaN`."""
+    lin = np.zeros((1, 4, 4), np.float32)
+    lin[0, 0, :3] = (1e-7, 1e-12, 0.0)
+    lin[0, 1, :3] = (3.0e-39, 1.0, 1e9)            # a subnormal float, and a large value
+    lin[0, 2, :3] = (np.nan, np.inf, -np.inf)
+    lin[0, 3, :3] = (-1e-7, 0.5, 0.25)
+    path = tmp_path / "dark.ppm"
+    rt.write_ppm_p3f(path, lin)
+    lines = open(path).read().split("\n")
+    body = lines[3:7]
+    assert not any("e" in l.lower().replace("inf", "").replace("nan", "") for l in body), body
+    first = body[0].split()
+    assert first[0].startswith("0.0000255999") and first[1].startswith("0.0000000002559") and first[2] == "0"
+    assert [float(t) for t in first] == [255.999 * float(np.float32(1e-7)), 255.999 * float(np.float32(1e-12)), 0.0]
+    second = [float(t) for t in body[1].split()]
+    assert second == [255.999 * float(np.float32(3.0e-39)), 255.999, 255.999 * float(np.float32(1e9))]
+    assert body[2].split() == ["NaN", "inf", "-inf"]
+    assert body[3].split()[0].startswith("-0.0000255999")
+
+
+def test_missing_rccl_is_an_error_code_not_a_crash(rt, tmp_path):
+    """rt_comm_id / rt_comm_init with an RCCL that cannot be loaded return RT_ERR_COMM and leave a message; the
+    process survives.  Runs in a child process because the library binds RCCL once per process."""
+    import subprocess
+    import sys
+    code = (
+        "import ctypes as C, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "import ray_tracing_amd._ffi as f\n"
+        "L = f.lib()\n"
+        "buf = (C.c_uint8 * 128)()\n"
+        "rc = L.rt_comm_id(C.byref(buf))\n"
+        "msg = (L.rt_last_error(None) or b'').decode()\n"
+        "print(rc, '|', msg)\n"
+        "rc2 = L.rt_comm_id(C.byref(buf))\n"
+        "sys.exit(0 if (rc == 10005 and rc2 == 10005 and 'cannot load RCCL' in msg and 'no-such-rccl' in msg) else 1)\n"
+    ) % ROOT
+    env = dict(os.environ, RT_RCCL_LIB=str(tmp_path / "no-such-rccl.so"))
+    res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, (res.returncode, res.stdout, res.stderr)
+
+
 def test_command_line_renderer_is_built():
     exe = os.path.join(ROOT, "ray_tracing_amd", "csrc", "rt_render")
     assert os.path.exists(exe) and os.access(exe, os.X_OK)

@@ -47,6 +47,52 @@ def check_render(oracle, hip, cam, spheres, params, exact=True, row0=0, rows=Non
     return got, (rgba, lin, seg)
 
 
+def test_reference_image_ppm_on_the_gpu(rt, hip):
+    """The reference's only known-answer file, cpu-implementation/image.ppm (256x144: sky gradient + one sphere
+    shaded by its normal, unrounded values 255.999 * colour; cut to tests/golden/image_ppm_fixture.npz), against
+    the HIP path itself -- no checker in between.
+      * sky: Camera::new (lib.rs:148-183), the pixel-centre ray (lib.rs:215-217 with offset 0 = the 1x1 grid
+        sampler) and miss shading (lib.rs:203-205 with blend 0.5) run on the GPU in f32 with an empty scene;
+        255.999 * linear must equal every sky value of the file to f32 rounding: the bound is 5e-5 on the 255
+        scale (2e-7 relative, three f32 roundings of a value near 1; observed maximum 1.8e-5).
+      * silhouette: rt_primary_hits on the file's one sphere {(0,0,-1), 0.5} (Sphere::hit's discriminant test,
+        lib.rs:96-125) must name exactly the file's 5,428 non-sky pixels."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "image_ppm_fixture.npz"))
+    W, H = int(g["width"]), int(g["height"])
+    sphere = np.unpackbits(g["sphere_bits"])[:W * H].astype(bool).reshape(H, W)
+    cam = rt.Camera.new_cpu(16.0 / 9.0, W)
+    assert (cam.image_width, cam.image_height) == (W, H)
+    p = rt.DeviceGUI(sample2_per_pixel=1, max_depth=5, t_min=0.001, t_max=float("inf"))
+    y, x = g["index"] // W, g["index"] % W
+    is_sky = ~sphere[y, x]
+    assert is_sky.sum() > 7000
+    for chunk in (0, 1):                                   # the fold kernel and the camera-ray-batch kernel
+        p.sample_chunk = chunk
+        hip.upload_scene(np.zeros(0, rt.SPHERE_DTYPE))
+        got = hip.render(cam, p, linear=True)
+        assert got["rays"] == W * H
+        vals = 255.999 * got["linear"][y, x, :3].astype(np.float64)
+        err = np.abs(vals - g["values"])[is_sky]
+        assert err.max() <= 5e-5, err.max()
+        assert (vals[is_sky][:, 2] == 255.999).all()       # blue of the sky is exactly 1.0, as in the file
+    one = np.zeros(1, rt.SPHERE_DTYPE)
+    one[0]["center"] = (0.0, 0.0, -1.0)
+    one[0]["radius"] = 0.5
+    one[0]["material"] = rt.RT_MAT_DIFFUSE
+    hip.upload_scene(one)
+    hits = hip.primary_hits(cam, rt.DeviceGUI(t_min=0.0, t_max=float("inf")))
+    assert (hits >= 0).sum() == 5428
+    assert np.array_equal(hits >= 0, sphere)
+    # the same silhouette from the render kernels: a black Lambertian sphere at depth 2 leaves exactly those pixels black
+    one[0]["albedo"] = (0.0, 0.0, 0.0)
+    hip.upload_scene(one)
+    for chunk in (0, 1):
+        q = rt.DeviceGUI(sample2_per_pixel=1, max_depth=2, t_min=0.0, t_max=float("inf"), sample_chunk=chunk)
+        lin = hip.render(cam, q, linear=True)["linear"]
+        assert np.array_equal(lin[..., 2] == 0.0, sphere)
+
+
 def test_c1_cpu_default_scene(oracle, rt, hip):
     """cpu-implementation defaults: 256x144, 64 spp, depth 20, 2 spheres, band reflectance."""
     cam = rt.Camera.new_cpu(16.0 / 9.0, 256)
@@ -184,12 +230,12 @@ def test_chunked_cpu_defaults_and_ragged_edges(oracle, rt, hip):
     check_render(oracle, hip, cam, rt.scene_gpu_default(), rt.DeviceGUI(samples_per_pixel=6, max_depth=0, sample_chunk=2))
 
 
-def test_camera_ray_batches_edge_cases(oracle, rt, hip, monkeypatch):
+def test_camera_ray_batches_edge_cases(oracle, rt, hip):
     """sample_chunk = 1 runs the kernel that traces camera rays 64 at a time and feeds bounce rays from a queue.
     Against the checker, bit for bit: the CPU app's defaults (per-column reflectance, rounding quantiser), ragged
     frame sizes and every block size, the grid sampler, depth limits 0, 1 and 2 (a path that ends at its first
     hit never enters the queue), a scene without spheres, one sample per pixel, a single row; and the same frame
-    from the item kernel (RT_NO_QUEUE=1) and from other unit shapes."""
+    from the item kernel (rt_debug_schedule no_queue) and from other unit shapes."""
     check_render(oracle, hip, rt.Camera.new_cpu(16.0 / 9.0, 256), rt.scene_cpu_default(), rt.cpu_params(64, 20, seed=0, sample_chunk=1))
     for width, block in ((250, 64), (67, 1024), (9, 0), (130, 320)):
         cam = rt.Camera.new(16.0 / 9.0, width)
@@ -205,11 +251,15 @@ def test_camera_ray_batches_edge_cases(oracle, rt, hip, monkeypatch):
     p = rt.DeviceGUI(samples_per_pixel=24, max_depth=30, seed=8, sample_chunk=1)
     got, _ = check_render(oracle, hip, cam, sp, p)
     check_render(oracle, hip, cam, sp, p, row0=41, rows=1)
-    for env, val in (("RT_NO_QUEUE", "1"), ("RT_UNIT", "8x8"), ("RT_UNIT", "16x1"), ("RT_UNIT", "1x1")):
-        monkeypatch.setenv(env, val)
+    for unit, no_queue, kernel in ((None, True, "rt_render"), ((8, 8), False, "rt_render_queue"), ((16, 1), False, "rt_render_queue"),
+                                   ((1, 1), False, "rt_render_queue")):
+        hip.debug_schedule(unit=unit, no_queue=no_queue)
         other = hip.render(cam, p, linear=True)
-        monkeypatch.delenv(env)
+        assert hip.last_kernel_name() == kernel
+        hip.debug_schedule()
         assert np.array_equal(other["linear"], got["linear"]) and other["rays"] == got["rays"]
+    with pytest.raises(rt.RtError):
+        hip.debug_schedule(unit=(3, 1))
 
 
 def test_randomised_scenes_all_modes(oracle, rt, hip):
@@ -244,6 +294,23 @@ def test_randomised_scenes_all_modes(oracle, rt, hip):
             check_render(oracle, hip, cam, sp, p, row0=row0, rows=rows)
         else:
             check_render(oracle, hip, cam, sp, p)
+
+
+def test_tiny_negative_run_sums(oracle, rt, hip):
+    """Negative albedos give run sums just below zero, where the fixed-point conversion has to carry
+    (floor -1, fraction rounding to 1): kernel and checker agree bit for bit in every accumulation mode."""
+    sp = np.zeros(1, rt.SPHERE_DTYPE)
+    sp[0]["center"] = (0.0, 0.0, -3.0)
+    sp[0]["radius"] = 2.5
+    sp[0]["material"] = 1
+    sp[0]["albedo"] = (-1e-10, -3e-9, -2e-8)
+    cam = rt.Camera.new_cpu(16.0 / 9.0, 64)
+    for chunk in (1, 2, 0):
+        got, _ = check_render(oracle, hip, cam, sp, rt.DeviceGUI(samples_per_pixel=4, max_depth=3, seed=2, sample_chunk=chunk))
+        if chunk == 0:
+            assert (got["linear"][..., :3] < 0).any()          # the fold keeps the tiny negative means
+        else:
+            assert (got["linear"][..., :3] > -1e-6).all()      # a missed carry would read -1/4 or +1/4
 
 
 def test_chunked_streaming_kernel(oracle, rt, hip):
@@ -331,7 +398,7 @@ def test_index_width_on_a_151_megapixel_frame(oracle, rt, hip):
         assert np.array_equal(got["rgba"][row0:row0 + rows], rgba)
 
 
-def test_unit_size_does_not_change_the_image(rt, hip, monkeypatch):
+def test_unit_size_does_not_change_the_image(rt, hip):
     """The shape of the pixel units the wavefronts take is a scheduling choice: exact accumulation makes the
     frame identical for all of them."""
     sp = rt.scene_book1_final(1)
@@ -339,10 +406,10 @@ def test_unit_size_does_not_change_the_image(rt, hip, monkeypatch):
     p = rt.DeviceGUI(samples_per_pixel=24, max_depth=30, seed=8, sample_chunk=2)
     hip.upload_scene(sp)
     frames = []
-    for u in ("8x1", "2x2", "4x1", "4x4", "16x1", "8x8", "64x1", "1x1"):
-        monkeypatch.setenv("RT_UNIT", u)
+    for u in ((8, 1), (2, 2), (4, 1), (4, 4), (16, 1), (8, 8), (64, 1), (1, 1)):
+        hip.debug_schedule(unit=u)
         frames.append(hip.render(cam, p, linear=True))
-    monkeypatch.delenv("RT_UNIT")
+    hip.debug_schedule()
     for f in frames[1:]:
         assert np.array_equal(f["linear"], frames[0]["linear"]) and f["rays"] == frames[0]["rays"]
 
@@ -485,8 +552,10 @@ def test_module_reload(rt, hip):
         hip.load_module(b"\x00" * 128)
 
 
-def test_command_line_renderer_writes_the_same_frame(rt, hip, tmp_path):
-    """tools/rt_render.cpp (C++ host mirror, include/rt_host.hpp) vs the Python mirror: same bytes."""
+def test_command_line_renderer_writes_the_same_frame(oracle, rt, tmp_path):
+    """tools/rt_render.cpp (C++ host mirror, include/rt_host.hpp -> C-ABI -> HIP) against the CPU checker: the
+    bytes of its P6 file are the checker's 8-bit frame, the numbers of its P3-float file (the reference's
+    image.ppm format) are 255.999 * the checker's linear radiance."""
     import os
     import subprocess
     exe = os.path.join(os.path.dirname(rt.__file__), "csrc", "rt_render")
@@ -496,22 +565,21 @@ def test_command_line_renderer_writes_the_same_frame(rt, hip, tmp_path):
     assert res.returncode == 0, res.stderr
     assert "Calculation took" in res.stdout
     cam = rt.Camera.new_cpu(16.0 / 9.0, 128)
-    hip.upload_scene(rt.scene_cpu_default())
-    ref = hip.render(cam, rt.cpu_params(16, 20, seed=3), linear=True)
+    rgba, lin, _ = oracle.render(oracle.camera_f32_from_rt(cam.block), rt.scene_cpu_default(), rt.cpu_params(16, 20, seed=3))
     data = open(out, "rb").read()
     head = b"P6\n128 72\n255\n"
     assert data.startswith(head)
-    assert np.array_equal(np.frombuffer(data[len(head):], np.uint8).reshape(72, 128, 3), ref["rgba"][..., :3])
+    assert np.array_equal(np.frombuffer(data[len(head):], np.uint8).reshape(72, 128, 3), rgba[..., :3])
     lines = open(p3f).read().split("\n")
     assert lines[:3] == ["P3", "128 72", "255"]
     vals = np.array([[float(t) for t in l.split()] for l in lines[3:3 + 128 * 72]])
-    assert np.array_equal(vals, 255.999 * ref["linear"][..., :3].astype(np.float64).reshape(-1, 3))
+    assert np.array_equal(vals, 255.999 * lin[..., :3].astype(np.float64).reshape(-1, 3))
     # the reference GPU app's defaults: 9 spheres, 4x4 grid samples, depth 4
     res = subprocess.run([exe, "--scene", "gpu", "--width", "160", "--out", str(tmp_path / "gpu.ppm")],
                          capture_output=True, text=True, timeout=120)
     assert res.returncode == 0, res.stderr
-    hip.upload_scene(rt.scene_gpu_default())
-    ref = hip.render(rt.Camera.new(16.0 / 9.0, 160), rt.DeviceGUI())
+    cam = rt.Camera.new(16.0 / 9.0, 160)
+    rgba, _, _ = oracle.render(oracle.camera_f32_from_rt(cam.block), rt.scene_gpu_default(), rt.DeviceGUI())
     data = open(tmp_path / "gpu.ppm", "rb").read()
     head = b"P6\n160 90\n255\n"
-    assert np.array_equal(np.frombuffer(data[len(head):], np.uint8).reshape(90, 160, 3), ref["rgba"][..., :3])
+    assert np.array_equal(np.frombuffer(data[len(head):], np.uint8).reshape(90, 160, 3), rgba[..., :3])

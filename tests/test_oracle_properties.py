@@ -156,3 +156,23 @@ def test_rng_streams_are_distinct(oracle):
     L.or_stream_init(C.byref(st), C.byref(inc), 1, 2, 3, 4)
     u = np.array([L.or_u01(L.or_pcg32_next(C.byref(st), inc.value)) for _ in range(20000)])
     assert 0.49 < u.mean() < 0.51 and 0.08 < u.var() < 0.087 and u.min() >= 0.0 and u.max() < 1.0
+
+
+def test_exact_accumulation_of_a_tiny_negative_run_sum(oracle):
+    """A run sum just below zero (possible with a negative albedo) has floor -1 and fraction x + 1, which rounds
+    to 1.0: the fixed-point conversion must carry it, not convert 2^32 to a 32-bit word.  With the carry the
+    chunked mean equals the fold's to rounding; without it the pixel would be off by 1 (or by -1)."""
+    import ray_tracing_amd as rt
+    sp = np.zeros(1, oracle.SPHERE_DTYPE)
+    sp[0]["center"] = (0.0, 0.0, -3.0)
+    sp[0]["radius"] = 2.5
+    sp[0]["material"] = 1
+    sp[0]["albedo"] = (-1e-10, -3e-9, -2e-8)
+    cam = oracle.camera_f32_from_d(oracle.camera_new_f64(16.0 / 9.0, 16))
+    for chunk in (1, 2):
+        p = rt.DeviceGUI(samples_per_pixel=4, max_depth=3, seed=2, sample_chunk=chunk)
+        fold = rt.DeviceGUI(samples_per_pixel=4, max_depth=3, seed=2, sample_chunk=0)
+        _, lin, _ = oracle.render(cam, sp, p)
+        _, ref, _ = oracle.render(cam, sp, fold)
+        assert (ref[..., :3] < 0).any()                       # the case is really exercised
+        assert np.abs(lin[..., :3].astype(np.float64) - ref[..., :3]).max() < 1e-6    # a missed carry is off by 1/spp = 0.25

@@ -19,6 +19,9 @@ else:
     sp = rt.scene_cpu_default(); cam = rt.Camera.new_cpu(16 / 9, width)
 p = rt.cpu_params(spp, depth, block_dim=block, sample_chunk=chunk) if scene == "cpu" else rt.DeviceGUI(samples_per_pixel=spp, max_depth=depth, seed=1, block_dim=block, sample_chunk=chunk)
 w = rt.HipWorld(0, sp)
+# scheduling experiments, from the environment of the A/B scripts: RT_UNIT=WxH, RT_NO_QUEUE=1
+_u = os.environ.get("RT_UNIT")
+w.debug_schedule(unit=tuple(int(v) for v in _u.split("x")) if _u else None, no_queue=os.environ.get("RT_NO_QUEUE") == "1")
 hs = os.environ.get("RT_HSACO")
 if hs:
     w.load_module(open(hs, "rb").read())

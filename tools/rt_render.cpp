@@ -66,11 +66,15 @@ int main(int argc, char** argv) {
             std::vector<float> kernel_ms(gpus, 0.0f);
             std::vector<std::string> errors(gpus);
             std::vector<double> wall(gpus, 0.0);
+            // every context (GPU set-up, scene upload) exists before any rank enters the collective comm_init: a GPU
+            // that cannot be set up ends the program here instead of leaving the other ranks waiting for it
+            std::vector<std::unique_ptr<rt::HipWorld>> ctx;
+            for (uint32_t r = 0; r < gpus; r++) ctx.push_back(std::make_unique<rt::HipWorld>((int)r, world));
             std::vector<std::thread> ranks;
             for (uint32_t r = 0; r < gpus; r++)
                 ranks.emplace_back([&, r] {
                     try {
-                        rt::HipWorld hip((int)r, world);
+                        rt::HipWorld& hip = *ctx[r];
                         hip.comm_init(id, gpus, r);
                         for (uint32_t f = 0; f < frames; f++) {
                             auto t0 = std::chrono::steady_clock::now();
