@@ -79,6 +79,22 @@ int rt_render_tiles_device(rt_ctx *ctx, const RtCamera *cam, const RtParams *par
                            uint32_t first_tile, uint32_t tile_stride, uint32_t n_tiles,
                            void *d_rgba, void *d_linear, uint64_t *rays_out);
 
+/* rt_render_tiles_device for callers that cannot allocate: code under HIP graph capture set-up, tight serving
+ * loops, harnesses that forbid hipMalloc.  No counterpart in the reference (whose CudaWorld allocates in its
+ * constructor only, ray_tracing.rs:106-127, and whose kernel needs no device memory beyond its arguments).
+ * Same arguments, same results, bit for bit.  The kernels' launch-wide counter block (128 bytes: segments traced,
+ * next pixel unit) lives in a statically allocated device array inside the library (256 bytes on every GPU the
+ * library runs on, held until the process ends) instead of memory from hipMalloc; this call performs no
+ * hipMalloc / hipFree and calls no allocating routine.  The block's size does not depend on the frame, the scene
+ * or the sample count; a code object loaded with rt_load_module that states a larger counter block than the
+ * array holds is rejected with RT_ERR_INVALID.  All contexts on one GPU share that GPU's array: calls that
+ * overlap on one GPU (two contexts driven from two threads) race and must be serialised by the caller.  The
+ * array is cleared at the start of every call.  The context, its scene (rt_upload_scene) and the output buffers
+ * are created beforehand, where allocation is allowed. */
+int rt_render_tiles_device_static(rt_ctx *ctx, const RtCamera *cam, const RtParams *params, uint32_t tile_rows,
+                                  uint32_t first_tile, uint32_t tile_stride, uint32_t n_tiles,
+                                  void *d_rgba, void *d_linear, uint64_t *rays_out);
+
 /* ---- one frame over the GPUs of a node, gathered to rank 0 with RCCL over xGMI -------------------------
  * One context per GPU and rank (one process per GPU, or one host thread per GPU).  The reference renders
  * on one GPU into a host frame the caller owns (CudaWorld::render, ray_tracing.rs:163-210);

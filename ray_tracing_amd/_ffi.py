@@ -56,6 +56,8 @@ SYMBOLS = {
                                  _vp, _vp, _vp, C.POINTER(C.c_uint64)]),
     "rt_render_tiles_device": (C.c_int, [_ctx, C.POINTER(RtCamera), C.POINTER(RtParams), C.c_uint32, C.c_uint32,
                                          C.c_uint32, C.c_uint32, _vp, _vp, C.POINTER(C.c_uint64)]),
+    "rt_render_tiles_device_static": (C.c_int, [_ctx, C.POINTER(RtCamera), C.POINTER(RtParams), C.c_uint32, C.c_uint32,
+                                                C.c_uint32, C.c_uint32, _vp, _vp, C.POINTER(C.c_uint64)]),
     "rt_comm_id": (C.c_int, [_vp]),
     "rt_comm_init": (C.c_int, [_ctx, _vp, C.c_uint32, C.c_uint32]),
     "rt_render_frame_sharded": (C.c_int, [_ctx, C.POINTER(RtCamera), C.POINTER(RtParams), C.c_uint32, _vp, C.POINTER(C.c_uint64)]),

@@ -232,10 +232,13 @@ class HipWorld:
             out["hits"] = hit
         return out
 
-    def render_tiles_device(self, camera, params, tile_rows, first_tile, tile_stride, n_tiles, d_rgba, d_linear=None):
-        """Interleaved row tiles into caller-owned device memory (integer device addresses)."""
+    def render_tiles_device(self, camera, params, tile_rows, first_tile, tile_stride, n_tiles, d_rgba, d_linear=None,
+                            static_scratch=False):
+        """Interleaved row tiles into caller-owned device memory (integer device addresses).  static_scratch: the
+        allocation-free entry point (counter block in the library's static device array)."""
         rays = C.c_uint64(0)
-        self._check(self._lib.rt_render_tiles_device(self._ctx, C.byref(camera.block), C.byref(params), tile_rows,
+        fn = self._lib.rt_render_tiles_device_static if static_scratch else self._lib.rt_render_tiles_device
+        self._check(fn(self._ctx, C.byref(camera.block), C.byref(params), tile_rows,
                                                      first_tile, tile_stride, n_tiles, C.c_void_p(d_rgba),
                                                      C.c_void_p(d_linear) if d_linear else None, C.byref(rays)))
         return rays.value, self._lib.rt_last_kernel_ms(self._ctx)

@@ -17,6 +17,9 @@
 
 #include "../../include/rt_hip.h"
 #include "rt_device.h"
+#include "rt_scratch.h"
+
+static_assert(RT_COUNTER_BYTES <= RT_SCRATCH_BYTES, "the kernels' counter block must fit the static scratch array");
 
 // The code object produced by `hipcc --offload-arch=gfx950 --genco rt_kernels.hip`.
 __asm__(
@@ -44,6 +47,8 @@ struct rt_ctx {
     bool have_scene = false;
     void *d_rgba = nullptr, *d_linear = nullptr, *d_hits = nullptr, *d_counter = nullptr;
     size_t counter_need = RT_COUNTER_BYTES, cap_counter = 0;   // counter block the loaded code object asks for; bytes d_counter holds
+    void* d_scratch = nullptr;          // this GPU's copy of the library's static device array (not owned; rt_scratch.hip)
+    int scratch_rc = 0;                 // why d_scratch is NULL, if it is
     // scheduling experiments (rt_debug_schedule): forced unit shape (0 = the library's choice), item kernel for sample_chunk 1
     uint32_t dbg_unit_w = 0, dbg_unit_h = 0;
     bool dbg_no_queue = false;
@@ -233,7 +238,8 @@ size_t lds_bytes(const rt_ctx* c, unsigned block, unsigned unit_pixels) {
 }
 
 // One render launch into device buffers; blocking; fills last_ms and (optionally) the segment count.
-// `counters`: RT_COUNTER_BYTES of device memory for the launch-wide counters.
+// `counters`: RT_COUNTER_BYTES of device memory for the launch-wide counters (the context's own block, or the
+// library's static array).  Allocates nothing.
 int launch_render(rt_ctx* c, const RtCamera* cam, const RtParams* p, RtLaunch L, void* d_rgba, void* d_linear,
                   uint64_t* rays_out, void* counters) {
     unsigned grid, block;
@@ -404,6 +410,9 @@ int rt_create(int device, rt_ctx** out) {
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail(hip_fail(c, e, "hipStreamCreate"));
     if ((e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess)
         return bail(hip_fail(c, e, "hipEventCreate"));
+    // this GPU's address of the static scratch array, looked up here, at set-up, with the GPU current; a failure
+    // only disables rt_render_tiles_device_static
+    c->scratch_rc = rt_scratch_lookup(device, &c->d_scratch, nullptr);
     if ((rc = load_image(c, rt_embedded_hsaco)) != 0) return bail(rc);
     *out = c;
     return 0;
@@ -524,6 +533,7 @@ int rt_render_rows(rt_ctx* c, const RtCamera* cam, const RtParams* p, uint32_t r
     return 0;
 }
 
+// rt_render_tiles_device and its allocation-free twin: same checks, same launch, different counter block
 static int render_tiles_into(rt_ctx* c, const RtCamera* cam, const RtParams* p, uint32_t tile_rows, uint32_t first_tile,
                              uint32_t tile_stride, uint32_t n_tiles, void* d_rgba, void* d_linear, uint64_t* rays_out,
                              void* counters) {
@@ -546,6 +556,28 @@ int rt_render_tiles_device(rt_ctx* c, const RtCamera* cam, const RtParams* p, ui
     if (rc) return rc;
     if ((rc = check_render(c, p))) return rc;
     return render_tiles_into(c, cam, p, tile_rows, first_tile, tile_stride, n_tiles, d_rgba, d_linear, rays_out, c->d_counter);
+}
+
+// No hipMalloc / hipFree / allocating routine on this path: argument checks, one occupancy query, hipMemsetAsync
+// of the counter block, the launch between two event records, a stream synchronisation and an 8-byte copy of the
+// segment count.  The counter block is the library's static device array (address looked up per GPU in rt_create).
+int rt_render_tiles_device_static(rt_ctx* c, const RtCamera* cam, const RtParams* p, uint32_t tile_rows,
+                                  uint32_t first_tile, uint32_t tile_stride, uint32_t n_tiles,
+                                  void* d_rgba, void* d_linear, uint64_t* rays_out) {
+    int rc = check_common(c, cam, p);
+    if (rc) return rc;
+    if ((rc = check_render(c, p))) return rc;
+    if (!c->d_scratch)
+        return fail(c, c->scratch_rc ? c->scratch_rc : RT_ERR_INVALID,
+                    std::string("static scratch array unavailable on this GPU: ") +
+                        (c->scratch_rc ? hipGetErrorName((hipError_t)c->scratch_rc) : "not looked up"));
+    // The one size that matters here: the counter block the loaded code object asks for (its rt_counter_bytes;
+    // code objects can be replaced at run time with rt_load_module) must fit the static array.  It does not grow
+    // with the frame, the scene or the sample count.
+    if (c->counter_need > RT_SCRATCH_BYTES)
+        return fail(c, RT_ERR_INVALID, "rt_render_tiles_device_static: the loaded code object needs " + std::to_string(c->counter_need) +
+                                           " bytes of counters, the static scratch array holds " + std::to_string(RT_SCRATCH_BYTES));
+    return render_tiles_into(c, cam, p, tile_rows, first_tile, tile_stride, n_tiles, d_rgba, d_linear, rays_out, c->d_scratch);
 }
 
 int rt_primary_hits(rt_ctx* c, const RtCamera* cam, const RtParams* p, uint32_t row0, uint32_t rows, int32_t* hit_out) {

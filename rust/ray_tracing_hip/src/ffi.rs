@@ -77,6 +77,10 @@ extern "C" {
     pub fn rt_render_tiles_device(ctx: *mut rt_ctx, cam: *const RtCamera, params: *const RtParams, tile_rows: u32,
                                   first_tile: u32, tile_stride: u32, n_tiles: u32, d_rgba: *mut u8, d_linear: *mut f32,
                                   rays_out: *mut u64) -> c_int;
+    /// The same without any allocation: counter block in the library's static device array.
+    pub fn rt_render_tiles_device_static(ctx: *mut rt_ctx, cam: *const RtCamera, params: *const RtParams, tile_rows: u32,
+                                         first_tile: u32, tile_stride: u32, n_tiles: u32, d_rgba: *mut u8,
+                                         d_linear: *mut f32, rays_out: *mut u64) -> c_int;
     pub fn rt_primary_hits(ctx: *mut rt_ctx, cam: *const RtCamera, params: *const RtParams, row0: u32, rows: u32,
                            hit_out: *mut i32) -> c_int;
     pub fn rt_show_random(ctx: *mut rt_ctx, width: u32, height: u32, seed: u64, norm: c_int, rgba_out: *mut u8) -> c_int;
