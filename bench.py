@@ -31,14 +31,44 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 FP32_VECTOR_PEAK_TFLOPS = 157.3   # MI355X vector FP32 peak: 256 CU x 2.4 GHz x 256 FLOP/clk/CU
 
 
+# name -> (description, width, spp, depth); scene and camera in workload()
+WORKLOADS = {
+    "c2": ("cpu-implementation default scene (2 spheres, per-column reflectance)", 1920, 100, 50),
+    "c3": ("book-1 final scene", 3840, 500, 50),
+    "c4": ("16,385-sphere grid scene (sphere list streamed through LDS)", 1920, 64, 16),
+    "c5": ("mirror/glass hall, deep bounces", 7680, 256, 100),
+}
+
+
+def workload(rt, args):
+    """(spheres, camera, params) of the chosen configuration."""
+    _, width, spp, depth = WORKLOADS[args.workload]
+    width, spp, depth = args.width or width, args.spp or spp, args.depth or depth
+    if args.workload == "c2":
+        sp, cam = rt.scene_cpu_default(), rt.Camera.new_cpu(16.0 / 9.0, width)
+        p = rt.cpu_params(spp, depth, seed=1, block_dim=args.block_dim, sample_chunk=args.sample_chunk)
+        return sp, cam, p
+    if args.workload == "c3":
+        sp, cam = rt.scene_book1_final(1), rt.Camera.look_at(16.0 / 9.0, width, 20.0, (13.0, 2.0, 3.0), (0.0, 0.0, 0.0))
+    elif args.workload == "c4":
+        sp, cam = rt.scene_grid(2, 128), rt.Camera.look_at(16.0 / 9.0, width, 40.0, (0.0, 30.0, 80.0), (0.0, 0.0, 0.0))
+    else:
+        sp, cam = rt.scene_mirror_hall(3, 64), rt.Camera.look_at(16.0 / 9.0, width, 90.0, (0.0, 0.0, -85.0), (0.0, 0.0, -70.0))
+    p = rt.DeviceGUI(samples_per_pixel=spp, max_depth=depth, seed=1, block_dim=args.block_dim, sample_chunk=args.sample_chunk)
+    return sp, cam, p
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--width", type=int, default=3840)
-    ap.add_argument("--spp", type=int, default=500)
-    ap.add_argument("--depth", type=int, default=50)
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS),
+                    help="c3 (default) is the configuration the metric is quoted on; the others are the remaining "
+                         "single-GPU configurations, for profiles of their kernels")
+    ap.add_argument("--width", type=int, default=0, help="0 = the workload's own")
+    ap.add_argument("--spp", type=int, default=0, help="0 = the workload's own")
+    ap.add_argument("--depth", type=int, default=0, help="0 = the workload's own")
     ap.add_argument("--block-dim", type=int, default=0)
     ap.add_argument("--sample-chunk", type=int, default=1,
                     help="samples per work item (RtParams.sample_chunk); 1 = every sample its own item (camera rays in batches); "
@@ -65,6 +95,25 @@ def cpu_baseline(rt, spheres, depth):
                       f"same camera and seed; f64 restatement of lib.rs, {seg} segments in {dt:.1f} s"}
 
 
+def code_object_sha256():
+    import hashlib
+    path = os.path.join(ROOT, "ray_tracing_amd", "csrc", "rt_kernels.hsaco")
+    return hashlib.sha256(open(path, "rb").read()).hexdigest() if os.path.exists(path) else None
+
+
+def stamped_traffic():
+    import glob
+    sha = code_object_sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")), reverse=True):
+        try:
+            rec = json.load(open(f))
+        except Exception:
+            continue
+        if sha and rec.get("code_object_sha256") == sha:
+            return rec.get("hbm_bytes_per_launch")
+    return None
+
+
 def main():
     args = ARGS
     import torch
@@ -87,23 +136,37 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
 
-    spheres = rt.scene_book1_final(1)
-    cam = rt.Camera.look_at(16.0 / 9.0, args.width, 20.0, (13.0, 2.0, 3.0), (0.0, 0.0, 0.0))
+    spheres, cam, params = workload(rt, args)
     W, H = cam.image_width, cam.image_height
-    params = rt.DeviceGUI(samples_per_pixel=args.spp, max_depth=args.depth, seed=1, block_dim=args.block_dim,
-                          sample_chunk=args.sample_chunk)
+    args.spp, args.depth, args.width = params.samples_per_pixel, params.max_depth, W
     hip = rt.HipWorld(local_rank, spheres)
 
     my_tiles = len(tiles.tiles_of_rank(H, rank, world))
     d_rgba = tiles.local_buffer(H, W, world, dev)          # compact per-rank buffer
-    gathered = [torch.empty_like(d_rgba) for _ in range(world)] if (world > 1 and rank == 0) else None
+    # rank 0: every rank's buffer back to back (the gather's destination) and the frame in image order
+    gathered = torch.empty((world,) + tuple(d_rgba.shape), dtype=torch.uint8, device=dev) if (world > 1 and rank == 0) else None
+    d_frame = torch.empty((H, W, 4), dtype=torch.uint8, device=dev) if (world > 1 and rank == 0) else None
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
     torch.cuda.synchronize()                               # buffers zero-filled before the library's stream writes them
 
     def step():
-        rays, ms = hip.render_tiles_device(cam, params, TILE_ROWS, rank, world, my_tiles, d_rgba.data_ptr())
-        # RCCL gather over xGMI (<= 4.2 MB per peer at 4K) + de-interleave on rank 0
-        frame = tiles.gather_frame(d_rgba, H, rank, world, gathered)
-        return rays, ms, frame
+        """One frame.  Returns (segments, kernel ms, gather ms, assemble ms, frame on rank 0)."""
+        rays, ms = hip.render_tiles_device(cam, params, TILE_ROWS, rank, world, my_tiles, d_rgba.data_ptr())   # blocking
+        if world == 1:
+            return rays, ms, 0.0, 0.0, d_rgba[:H]
+        # RCCL gather over xGMI (<= 4.2 MB per peer at 4K) into the contiguous buffer, then the library's copy
+        # kernel puts the tiles in image order.  The gather's time on rank 0 includes waiting for the slowest rank.
+        ev[0].record()
+        dist.gather(d_rgba, [gathered[r] for r in range(world)] if rank == 0 else None, dst=0)
+        ev[1].record()
+        ev[1].synchronize()                                # d_rgba is rewritten by the next render on another stream
+        gather_ms = ev[0].elapsed_time(ev[1])
+        assemble_ms = 0.0
+        if rank == 0:
+            t = time.perf_counter()
+            hip.assemble_tiles(gathered.data_ptr(), W, H, TILE_ROWS, world, d_frame.data_ptr())               # blocking
+            assemble_ms = (time.perf_counter() - t) * 1e3
+        return rays, ms, gather_ms, assemble_ms, d_frame
 
     def fence():
         if world > 1:
@@ -114,22 +177,30 @@ def main():
         step()
     fence()
     t0 = time.perf_counter()
-    rays_total, kernel_ms = 0, []
+    rays_total, kernel_ms, gather_ms, assemble_ms = 0, [], [], []
     frame = None
     for _ in range(args.steps):
-        rays, ms, frame = step()
+        rays, ms, gms, ams, frame = step()
         rays_total += rays
         kernel_ms.append(ms)
+        gather_ms.append(gms)
+        assemble_ms.append(ams)
     fence()
     elapsed = time.perf_counter() - t0
 
-    stats = torch.tensor([elapsed, float(rays_total), sum(kernel_ms) / max(1, len(kernel_ms))], dtype=torch.float64, device=dev)
+    mean = lambda v: sum(v) / max(1, len(v))
+    stats = torch.tensor([elapsed, float(rays_total), mean(kernel_ms), mean(gather_ms)], dtype=torch.float64, device=dev)
+    per_rank = None
     if world > 1:
         tmax = stats.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = stats.clone()
         dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
         elapsed_max, rays_all, kms_max = tmax[0].item(), tsum[1].item(), tmax[2].item()
+        every = [torch.empty_like(stats) for _ in range(world)]
+        dist.all_gather(every, stats)
+        per_rank = {"wall_s": [e[0].item() for e in every], "segments": [e[1].item() for e in every],
+                    "kernel_ms": [e[2].item() for e in every], "gather_ms": [e[3].item() for e in every]}
     else:
         elapsed_max, rays_all, kms_max = stats[0].item(), stats[1].item(), stats[2].item()
 
@@ -140,13 +211,11 @@ def main():
         rank0_rays_per_launch = rays_total / max(1, args.steps)
         k_ms = sum(kernel_ms) / max(1, len(kernel_ms))
         achieved = rank0_rays_per_launch * flop_per_segment / (k_ms * 1e-3) * 1e-12 if k_ms > 0 else 0.0
+        # HBM bytes per launch from the PMC passes kept under profiles/ -- only if they were taken with the code
+        # object this run executes (the file is stamped with its SHA-256) and on this workload; else null
         traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
-        if os.path.exists(pmc) and world == 1 and (args.width, args.spp, args.depth) == (3840, 500, 50):
-            try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        if world == 1 and (args.workload, args.width, args.spp, args.depth, args.sample_chunk) == ("c3", 3840, 500, 50, 1):
+            traffic = stamped_traffic()
         out = {
             "metric": "Mrays/s (primary+bounce) at 1/2/4/8 MI355X + % of FP32 VALU peak",
             "value": rays_all / elapsed_max * 1e-6,
@@ -160,7 +229,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"book-1 final scene, {n_sph} spheres, {W}x{H}, {args.spp} spp, max depth {args.depth}, "
+            "config": {"workload": f"{args.workload}: {WORKLOADS[args.workload][0]}, {n_sph} spheres, {W}x{H}, {args.spp} spp, max depth {args.depth}, "
                                    f"jittered sampler, seed 1, sample_chunk {args.sample_chunk}; frame split into interleaved {TILE_ROWS}-row tiles over "
                                    f"{world} GPU(s), RCCL gather to rank 0",
                        "spheres": n_sph, "width": W, "height": H, "spp": args.spp, "max_depth": args.depth, "sample_chunk": args.sample_chunk,
@@ -170,9 +239,13 @@ def main():
                          "kernel": hip.last_kernel_name(), "kernel_ms": k_ms, "flop_per_segment": flop_per_segment,
                          "segments_per_launch": rank0_rays_per_launch},
             "kernel_ms_max_over_ranks": kms_max,
+            # where a multi-GPU step goes: each rank's own render kernel, its gather (on rank 0 this includes the
+            # wait for the slowest rank, i.e. load imbalance and launch skew), rank 0's copy kernel
+            "per_rank": per_rank,
+            "rank0_gather_ms": mean(gather_ms), "rank0_assemble_ms": mean(assemble_ms),
             "checksum": int(frame.to(torch.int64).sum().item()) if frame is not None else None,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.workload == "c3":
             out["cpu_baseline"] = cpu_baseline(rt, spheres, args.depth)
         print(json.dumps(out), flush=True)
     hip.close()

@@ -36,13 +36,26 @@ for f in glob.glob(os.path.join(src, "pmc_*", "**", "*counter_collection.csv"), 
         pmc[name] = sum(vals) / len(vals)
 
 seg = bench["roofline"]["segments_per_launch"]
+cfg = bench["config"]
+n_sph = cfg["spheres"]
+n_pad = (n_sph + 7) // 8 * 8
+sha_file = os.path.join(src, "code_object.sha256")
+sha = open(sha_file).read().strip() if os.path.exists(sha_file) else None
 lines = []
 w = lines.append
-w(f"# {tag}: rocprofv3 summary of `python bench.py` (book-1 final scene, 3840x2160, 500 spp, depth 50, 1 x MI355X)")
+w(f"# {tag}: rocprofv3 summary of `python bench.py --workload {cfg['workload'].split(':')[0]}` ({cfg['workload'].split(';')[0]}; 1 x MI355X)")
+w(f"code object rt_kernels.hsaco sha256 {sha}")
 w(f"kernel-trace: {KERNEL} {len(durs)} dispatches, durations ms {['%.1f' % d for d in durs]}, average {sum(durs) / len(durs):.1f} ms")
 w(f"bench.py in the same run: kernel_ms {bench['roofline']['kernel_ms']:.1f} (HIP events in the library), value {bench['value']:.1f} Mrays/s, "
-  f"roofline {bench['roofline']['achieved']:.2f} TFLOP/s = {100 * bench['roofline']['frac']:.1f} % of {bench['roofline']['peak']}")
+  f"roofline {bench['roofline']['achieved']:.2f} TFLOP/s = {100 * bench['roofline']['frac']:.1f} % of {bench['roofline']['peak']} "
+  f"({bench['roofline']['flop_per_segment']} FLOP per segment)")
 w(f"dispatch: {meta}")
+waves = int(meta.get("Grid_Size", 0)) // 64 if meta else 0
+w(f"  launched: Grid_Size / 64 = {waves} wavefronts.  rocprofv3's VGPR_Count is half of what the compiler reports for the same kernel")
+w("  (hipcc -Rpass-analysis=kernel-resource-usage: rt_render_queue 96 VGPRs, which is what 5 waves per SIMD of a 512-register file")
+w("  allow and what the measured residency below confirms; the dispatch row divides the descriptor's 8-register granules by two).")
+if pmc.get("SQ_WAVES") and waves:
+    w(f"  SQ_WAVES reads {pmc['SQ_WAVES']:.0f} = {pmc['SQ_WAVES'] / waves:.2f} x the wavefronts launched.")
 w("")
 w("PMC (separate passes, one dispatch each, summed over the chip):")
 for k in sorted(pmc):
@@ -51,8 +64,8 @@ w("")
 w("derived:")
 if pmc.get("SQ_INSTS_VALU"):
     w(f"  ray segments per launch            {seg:.0f}")
-    w(f"  VALU wave-instructions per segment {pmc['SQ_INSTS_VALU'] / seg * 64:.1f} x 64 (the item kernel's trip: 488 x 9 = 4392 in the scan; camera rays 488 x 5)")
-    w(f"  active lanes per VALU instruction  {pmc['SQ_THREAD_CYCLES_VALU'] / pmc['SQ_INSTS_VALU']:.1f} of 64 ({100 * pmc['SQ_THREAD_CYCLES_VALU'] / pmc['SQ_INSTS_VALU'] / 64:.1f} %)")
+    w(f"  VALU wave-instructions per segment {pmc['SQ_INSTS_VALU'] / seg * 64:.1f} x 64 (scan alone: {n_pad} x 9 = {n_pad * 9} per bounce segment, {n_pad} x 5 per camera ray)")
+    w(f"  active lanes per VALU instruction  {pmc['SQ_THREAD_CYCLES_VALU'] / pmc['SQ_INSTS_VALU']:.1f} of 64 ({100 * pmc['SQ_THREAD_CYCLES_VALU'] / pmc['SQ_INSTS_VALU'] / 64:.1f} %)  <- branch divergence")
     w(f"  LDS instructions per VALU instr    {pmc['SQ_INSTS_LDS'] / pmc['SQ_INSTS_VALU']:.3f}")
     w(f"  SALU instructions per VALU instr   {pmc['SQ_INSTS_SALU'] / pmc['SQ_INSTS_VALU']:.3f}")
 if pmc.get("SQ_LDS_IDX_ACTIVE"):
@@ -62,7 +75,12 @@ if pmc.get("GRBM_GUI_ACTIVE"):
     clk = pmc["GRBM_GUI_ACTIVE"] / 8 / k_s
     w(f"  effective shader clock             {clk / 1e9:.2f} GHz (GRBM_GUI_ACTIVE / 8 XCDs / kernel time)")
     w(f"  VALU wave-instructions per SIMD per cycle  {pmc['SQ_INSTS_VALU'] / 1024 / (pmc['GRBM_GUI_ACTIVE'] / 8):.3f} (tools/microbench/vgpr_bank: a pure v_fma_f32 stream issues 0.42 at 8 waves per SIMD, 0.36 at 4)")
-    w(f"  resident waves per SIMD (SQ_WAVE_CYCLES*4 / cycles / 1024)  {pmc['SQ_WAVE_CYCLES'] * 4 / (pmc['GRBM_GUI_ACTIVE'] / 8) / 1024:.2f}" if pmc.get("SQ_WAVE_CYCLES") else "")
+    if pmc.get("SQ_WAVE_CYCLES"):
+        w(f"  resident waves per SIMD (SQ_WAVE_CYCLES*4 / cycles / 1024)  {pmc['SQ_WAVE_CYCLES'] * 4 / (pmc['GRBM_GUI_ACTIVE'] / 8) / 1024:.2f}  <- occupancy")
+if pmc.get("SQ_INSTS_VMEM_RD") is not None and "SQ_INSTS_VMEM_RD" in pmc:
+    w(f"  vector-memory wave-instructions per segment x 64: reads {pmc['SQ_INSTS_VMEM_RD'] / seg * 64:.2f}, writes {pmc['SQ_INSTS_VMEM_WR'] / seg * 64:.2f} "
+      f"(global + scratch; a spill-free kernel writes only finished pixels), branches {pmc['SQ_INSTS_BRANCH'] / seg * 64:.1f}, "
+      f"scalar loads {pmc['SQ_INSTS_SMEM'] / seg * 64:.2f}, MFMA {pmc.get('SQ_INSTS_MFMA', 0):.0f}")
 hbm = None
 if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
     # FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half of a wide coalesced read stream
@@ -70,14 +88,13 @@ if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
     write = pmc["WRITE_SIZE"] * 1024
     hbm = fetch + write
     w(f"  HBM traffic per launch             {hbm / 1e6:.1f} MB (FETCH_SIZE {pmc['FETCH_SIZE']:.0f} KiB x2 gfx950 correction + WRITE_SIZE {pmc['WRITE_SIZE']:.0f} KiB);"
-      f" algorithmic bytes: 3840*2160*4 B frame = 33.2 MB + 31 KB scene")
+      f" algorithmic bytes: {cfg['width']}*{cfg['height']}*4 B frame = {cfg['width'] * cfg['height'] * 4 / 1e6:.1f} MB + {n_pad * 68 / 1e3:.0f} KB scene")
 open(os.path.join(dst, f"{tag}_rocprof_summary.txt"), "w").write("\n".join(l for l in lines) + "\n")
 if hbm is not None:
     json.dump({"hbm_bytes_per_launch": hbm, "fetch_size_kib": pmc["FETCH_SIZE"], "write_size_kib": pmc["WRITE_SIZE"],
+               "code_object_sha256": sha, "workload": cfg["workload"],
                "note": "rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in separate passes of bench.py --steps 1; FETCH_SIZE doubled (gfx950 correction)"},
               open(os.path.join(dst, f"{tag}_hbm_traffic.json"), "w"))
-# the bench line of the traced run, with the traffic figure of this run's own PMC passes
-if hbm is not None:
-    bench["roofline"]["traffic"] = hbm
-open(os.path.join(dst, f"{tag}_bench_1gpu.json"), "w").write(json.dumps(bench) + "\n")
+bench["roofline"]["traffic"] = hbm
+json.dump(bench, open(os.path.join(dst, f"{tag}_bench_1gpu.json"), "w"))
 print("\n".join(lines))
