@@ -142,8 +142,8 @@ const char *rt_last_kernel_name(const rt_ctx *ctx);
  * out[8] = pixel units handed out (+ one failed request per wavefront).  The others are filled only by a code
  * object built with -DRT_STATS: 1..7 loop-trip counts (scan passes, candidates listed, exact-test rounds,
  * decode rounds, unit-vector tries, drain calls, unit-vector rounds), 9..15 shader cycles per kernel section
- * (scan filter, decode, exact tests, hit + scatter, sky / next sample, hand-out, rest).  No counterpart in the
- * reference. */
+ * (scan filter of bounce rays, decode, exact tests, hit + scatter, sky / accumulate, hand-out + queue + camera-ray
+ * generation, scan filter of camera rays).  No counterpart in the reference. */
 int rt_debug_counters(rt_ctx *ctx, uint64_t out[16]);
 
 /* Diagnostic: scheduling experiments on this context.  unit_w x unit_h (powers of two, at most 64 pixels;

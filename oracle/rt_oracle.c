@@ -171,10 +171,11 @@ void or32_show_random(uint32_t width, uint32_t height, uint64_t seed, int norm, 
             for (int k = 0; k < 3; k++) rgb[k] = or_u01(or_pcg32_next(&st, inc));
         } else {     /* random_norm_float3, library.cu:25-31, with the rejection sampler used by the renderer */
             rgb[0] = 1.0f; rgb[1] = 0.0f; rgb[2] = 0.0f;
-            for (int i = 0; i < 20; i++) {
-                float x = fmaf(2.0f, or_u01(or_pcg32_next(&st, inc)), -1.0f);
-                float y = fmaf(2.0f, or_u01(or_pcg32_next(&st, inc)), -1.0f);
-                float z = fmaf(2.0f, or_u01(or_pcg32_next(&st, inc)), -1.0f);
+            for (int i = 0; i < 20; i++) { /* one try = two outputs cut into three 21-bit coordinates */
+                uint32_t a = or_pcg32_next(&st, inc), b = or_pcg32_next(&st, inc);
+                float x = fmaf((float)(a >> 11), 0x1p-20f, -1.0f);
+                float y = fmaf((float)(b >> 11), 0x1p-20f, -1.0f);
+                float z = fmaf((float)(((a & 0x7ffu) << 10) | (b & 0x3ffu)), 0x1p-20f, -1.0f);
                 float d = fmaf(z, z, fmaf(y, y, x * x));
                 if (d <= 1.0f) {
                     float inv = 1.0f / sqrtf(d);

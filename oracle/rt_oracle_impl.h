@@ -54,12 +54,16 @@ typedef struct { uint64_t state, inc; } NAME(Rng);
 static inline REAL NAME(rand01)(NAME(Rng) *g) { return R(or_u01(or_pcg32_next(&g->state, g->inc))); }
 
 /* random_unit_vector: rejection in [-1,1)^3, accept p.p <= 1, normalise (lib.rs:31-47), with the
- * GPU path's bound of 20 tries and its (1,0,0) fallback (library.cu:25-31). */
+ * GPU path's bound of 20 tries and its (1,0,0) fallback (library.cu:25-31).  One try takes two generator
+ * outputs a, b and cuts three 21-bit coordinates out of their 64 bits: x = a >> 11, y = b >> 11,
+ * z = (a & 0x7ff) << 10 | (b & 0x3ff); a coordinate is k * 2^-20 - 1 (exact in single precision). */
 static inline V3 NAME(random_unit_vector)(NAME(Rng) *g) {
     for (int i = 0; i < 20; i++) {
-        REAL x = MADD(R(2), NAME(rand01)(g), R(-1));
-        REAL y = MADD(R(2), NAME(rand01)(g), R(-1));
-        REAL z = MADD(R(2), NAME(rand01)(g), R(-1));
+        uint32_t a = or_pcg32_next(&g->state, g->inc);
+        uint32_t b = or_pcg32_next(&g->state, g->inc);
+        REAL x = MADD(R(a >> 11), R(0x1p-20), R(-1));
+        REAL y = MADD(R(b >> 11), R(0x1p-20), R(-1));
+        REAL z = MADD(R(((a & 0x7ffu) << 10) | (b & 0x3ffu)), R(0x1p-20), R(-1));
         V3 p = NAME(v3)(x, y, z);
         if (NAME(dot)(p, p) <= R(1)) return NAME(unit)(p);
     }
@@ -174,11 +178,22 @@ void NAME(miss_color)(const REAL dir[3], REAL blend, REAL rgb[3]) {
 }
 
 /* Material::scatter (library.cu:131-149,175-183) plus the book's dielectric.  Returns the new direction;
- * *atten receives the attenuation.  Stream draw order: one uniform (dielectric choice), then the
- * unit-vector rejection triples. */
-static inline V3 NAME(scatter)(const NAME(Sph) *sp, V3 d, const NAME(Hit) *h, NAME(Rng) *g, uint32_t flags, V3 *atten) {
-    REAL u_choice = NAME(rand01)(g);
-    V3 ru = NAME(random_unit_vector)(g);
+ * *atten receives the attenuation.  The segment's stream (seed, pixel, sample, k) is started only by a
+ * material that draws from it: Lambertian and metal with fuzz > 0 draw the unit-vector tries, glass draws one
+ * uniform (reflect or refract), a mirror (fuzz 0) draws nothing. */
+static inline V3 NAME(scatter)(const NAME(Sph) *sp, V3 d, const NAME(Hit) *h, uint64_t seed, uint32_t pixel,
+                               uint32_t sample, uint32_t k, uint32_t flags, V3 *atten) {
+    const int band = (flags & RT_FLAG_BAND_ALBEDO) != 0;
+    const int glass = !band && sp->mat == RT_MAT_DIELECTRIC;
+    const int wants_unit = band || sp->mat == RT_MAT_DIFFUSE || (sp->mat == RT_MAT_REFLECT && sp->param != R(0));
+    REAL u_choice = R(0);
+    V3 ru = NAME(v3)(R(0), R(0), R(0));
+    if (glass || wants_unit) {
+        NAME(Rng) g;
+        or_stream_init(&g.state, &g.inc, seed, pixel, sample, k);
+        if (glass) u_choice = NAME(rand01)(&g);
+        else ru = NAME(random_unit_vector)(&g);
+    }
     V3 n = h->n;
     *atten = sp->albedo;
     if ((flags & RT_FLAG_BAND_ALBEDO) || sp->mat == RT_MAT_DIFFUSE) {
@@ -194,6 +209,8 @@ static inline V3 NAME(scatter)(const NAME(Sph) *sp, V3 d, const NAME(Hit) *h, NA
         REAL k = R(2) * NAME(dot)(d, n);
         V3 refl = NAME(v3)(NMADD(n.x, k, d.x), NMADD(n.y, k, d.y), NMADD(n.z, k, d.z));
         V3 ur = NAME(unit)(refl);
+        /* fuzz * random (library.cu:147) adds nothing when fuzz is 0: the mirror direction itself */
+        if (!wants_unit) return ur;
         return NAME(v3)(MADD(ru.x, sp->param, ur.x), MADD(ru.y, sp->param, ur.y), MADD(ru.z, sp->param, ur.z));
     }
     /* Dielectric: not in the reference; "Ray Tracing in One Weekend" section 11 (Snell + Schlick). */
@@ -230,10 +247,8 @@ static inline V3 NAME(ray_color)(const NAME(Sph) *w, uint32_t n, V3 o, V3 d, con
         (*nseg)++;
         NAME(Hit) h = NAME(closest_hit)(w, n, o, d, t_min, t_max, flags);
         if (h.idx >= 0) {
-            NAME(Rng) g;
-            or_stream_init(&g.state, &g.inc, prm->seed, pixel, sample, seg + 1);
             V3 atten;
-            V3 nd = NAME(scatter)(&w[h.idx], d, &h, &g, flags, &atten);
+            V3 nd = NAME(scatter)(&w[h.idx], d, &h, prm->seed, pixel, sample, seg + 1, flags, &atten);
             o = h.p;
             d = nd;
             if (flags & RT_FLAG_BAND_ALBEDO) nb++;

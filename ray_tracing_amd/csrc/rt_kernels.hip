@@ -94,18 +94,19 @@ RT_DEV Rng stream_init(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t 
 RT_DEV float rand01(Rng& g) { return (float)(pcg_next(g) >> 8) * 0x1p-24f; }
 
 // Rejection in [-1,1)^3, accept p.p <= 1, normalise (lib.rs:31-47); at most 20 tries, then (1,0,0)
-// (library.cu:25-31).
+// (library.cu:25-31).  One try takes two generator outputs a, b and cuts three 21-bit coordinates out of their
+// 64 bits: x = a >> 11, y = b >> 11, z = (a & 0x7ff) << 10 | (b & 0x3ff); a coordinate is k * 2^-20 - 1, exact.
+// (Two 64-bit multiplies per try instead of three: integer multiplies run at a quarter of the fp32 rate.)
 RT_DEV V3 random_unit_vector(Rng& g, Stats& st) {
     V3 p = v3(1.0f, 0.0f, 0.0f);
     bool done = false;
     for (int i = 0; i < 20 && !done; i++) {
         st.add(5, 1u);
         st.wave(7);
-        // 2 * rand01 - 1 in one rounding, as the checker's fmaf(2, rand01, -1): k * 2^-24 is exact, so both are
-        // the single rounding of k * 2^-23 - 1
-        float x = fmaf((float)(pcg_next(g) >> 8), 0x1p-23f, -1.0f);
-        float y = fmaf((float)(pcg_next(g) >> 8), 0x1p-23f, -1.0f);
-        float z = fmaf((float)(pcg_next(g) >> 8), 0x1p-23f, -1.0f);
+        const uint32_t a = pcg_next(g), b = pcg_next(g);
+        float x = fmaf((float)(a >> 11), 0x1p-20f, -1.0f);
+        float y = fmaf((float)(b >> 11), 0x1p-20f, -1.0f);
+        float z = fmaf((float)(((a & 0x7ffu) << 10) | (b & 0x3ffu)), 0x1p-20f, -1.0f);
         V3 q = v3(x, y, z);
         if (vdot(q, q) <= 1.0f) { p = q; done = true; }
     }
@@ -247,7 +248,6 @@ RT_DEV void scan_tile(const Tile& tile, uint32_t count, int base, V3 T,
     const float e = -vdot(uf, op);
     const V3 w = v3(2.0f * op.x, 2.0f * op.y, 2.0f * op.z);
     const float k0 = -(vdot(op, op) * (1.0f - 0x1p-18f));
-    st.lap(15);
     for (uint32_t blk = 0; blk < count; blk += 32u) {
         const uint32_t k = (count - blk) < 32u ? (count - blk) : 32u;   // spheres in this block, multiple of 8
         uint32_t miss = 0u;                                            // bit j set: sphere blk + (k-1-j) cannot be hit
@@ -297,9 +297,11 @@ RT_DEV void scan_primary(const float4* __restrict__ geo0, const Tile& tile, uint
                 miss = __builtin_amdgcn_alignbit(miss, __float_as_uint(key), 31u);
             }
         }
+        st.lap(15);
         decode_block(tile, base, blk, k, miss, o, d, a, t_min, b, c, st);
     }
     drain(tile, base, c, o, d, a, t_min, b, st);
+    st.lap(11);
 }
 
 // ---------------------------------------------------------------- shading
@@ -337,21 +339,30 @@ RT_DEV V3 sky(V3 d, float blend) {
     return v3(fmaf(a, 0.5f, om), fmaf(a, 0.7f, om), fmaf(a, 1.0f, om));
 }
 
-// Material::scatter (library.cu:131-149,175-183) plus the book's dielectric.  Draw order: one uniform
-// (dielectric choice), then the unit-vector rejection triples.
-RT_DEV V3 scatter(uint32_t mat, float param, V3 d, const HitInfo& h, Rng& g, uint32_t flags, Stats& st) {
-    float u_choice = rand01(g);
-#ifdef RT_EXP_UNIT2
-    {   // cost experiment: one more unit vector from a copy of the stream, kept alive and unused
-        Rng g2 = g;
-        g2.state ^= 0x9E3779B97F4A7C15ULL;
-        V3 r2 = random_unit_vector(g2, st);
-        asm volatile("" :: "v"(r2.x), "v"(r2.y), "v"(r2.z));
-    }
-#endif
-    // glass never looks at the random vector, and the stream ends with this segment: its lanes skip the loop
+// Material::scatter (library.cu:131-149,175-183) plus the book's dielectric.  The segment's stream
+// (seed, pixel, sample, k) is started only by a material that draws from it: Lambertian and metal with
+// fuzz > 0 draw the unit-vector tries, glass draws one uniform (reflect or refract), a mirror (fuzz 0) draws
+// nothing -- a wavefront whose lanes all hit mirrors does no integer work here at all.
+RT_DEV V3 scatter(uint32_t mat, float param, V3 d, const HitInfo& h, uint64_t seed, uint32_t pixel, uint32_t s,
+                  uint32_t k, uint32_t flags, Stats& st) {
+    const bool band = (flags & RT_FLAG_BAND_ALBEDO) != 0u;
+    const bool glass = !band && mat == RT_MAT_DIELECTRIC;
+    const bool wants_unit = band || mat == RT_MAT_DIFFUSE || (mat == RT_MAT_REFLECT && param != 0.0f);
+    float u_choice = 0.0f;
     V3 ru = v3(0.0f, 0.0f, 0.0f);
-    if ((flags & RT_FLAG_BAND_ALBEDO) || mat != RT_MAT_DIELECTRIC) ru = random_unit_vector(g, st);
+    if (glass || wants_unit) {
+        Rng g = stream_init(seed, pixel, s, k);
+        if (glass) u_choice = rand01(g);
+#ifdef RT_EXP_UNIT2
+        if (wants_unit) {   // cost experiment: one more unit vector from a copy of the stream, kept alive and unused
+            Rng g2 = g;
+            g2.state ^= 0x9E3779B97F4A7C15ULL;
+            V3 r2 = random_unit_vector(g2, st);
+            asm volatile("" :: "v"(r2.x), "v"(r2.y), "v"(r2.z));
+        }
+#endif
+        if (wants_unit) ru = random_unit_vector(g, st);
+    }
     V3 n = h.n;
     V3 out;
     if ((flags & RT_FLAG_BAND_ALBEDO) || mat == RT_MAT_DIFFUSE) {
@@ -364,7 +375,8 @@ RT_DEV V3 scatter(uint32_t mat, float param, V3 d, const HitInfo& h, Rng& g, uin
         float k = 2.0f * vdot(d, n);                             // floatN_helper.cu:124-127
         V3 refl = v3(fmaf(-n.x, k, d.x), fmaf(-n.y, k, d.y), fmaf(-n.z, k, d.z));
         V3 ur = vunit(refl);                                     // library.cu:146-147
-        out = v3(fmaf(ru.x, param, ur.x), fmaf(ru.y, param, ur.y), fmaf(ru.z, param, ur.z));
+        out = ur;                                                // fuzz 0: fuzz * random adds nothing
+        if (wants_unit) out = v3(fmaf(ru.x, param, ur.x), fmaf(ru.y, param, ur.y), fmaf(ru.z, param, ur.z));
     } else {
         // Dielectric ("Ray Tracing in One Weekend" section 11): Snell refraction, Schlick reflectance.
         float ri = h.front ? 1.0f / param : param;
@@ -689,8 +701,7 @@ RT_DEV void render_body(const Scene& sc, uint32_t* __restrict__ rgba, float4* __
                 const float4 al = sc.shade[2 * b.idx + 1];
                 const uint32_t mat = sc.mat[b.idx];
                 HitInfo h = finish_hit(cr, b.t, o, d, flags);
-                Rng g = stream_init(seed, it.pixel, it.s, seg + 1u);
-                V3 nd = scatter(mat, al.w, d, h, g, flags, st);
+                V3 nd = scatter(mat, al.w, d, h, seed, it.pixel, it.s, seg + 1u, flags, st);
                 o = h.p;
                 d = nd;
                 if (flags & RT_FLAG_BAND_ALBEDO) {
@@ -787,14 +798,14 @@ RT_DEV bool shade_segment(const Scene& sc, const RtLaunch& L, uint64_t seed, con
         const float4 al = sc.shade[2 * b.idx + 1];
         const uint32_t mat = sc.mat[b.idx];
         HitInfo h = finish_hit(cr, b.t, p.o, p.d, flags);
-        Rng g = stream_init(seed, pixel, s, p.seg + 1u);
-        V3 nd = scatter(mat, al.w, p.d, h, g, flags, st);
+        V3 nd = scatter(mat, al.w, p.d, h, seed, pixel, s, p.seg + 1u, flags, st);
         p.o = h.p;
         p.d = nd;
         if (flags & RT_FLAG_BAND_ALBEDO) p.nb++;
         else p.thr = v3(p.thr.x * al.x, p.thr.y * al.y, p.thr.z * al.z);
         p.seg++;
         color = v3(0.0f, 0.0f, 0.0f);
+        st.lap(12);
         return p.seg == L.max_depth;
     }
     if (flags & RT_FLAG_BAND_ALBEDO) {
@@ -804,6 +815,7 @@ RT_DEV bool shade_segment(const Scene& sc, const RtLaunch& L, uint64_t seed, con
         V3 sk = sky(p.d, 0.5f);
         color = v3(p.thr.x * sk.x, p.thr.y * sk.y, p.thr.z * sk.z);
     }
+    st.lap(13);
     return true;
 }
 
@@ -887,6 +899,7 @@ RT_DEV void primary_batch(const Scene& sc, const Tile& tile, const float4* __res
         Best b;
         b.t = L.t_max;
         b.idx = -1;
+        st.lap(14);
         scan_primary(geo0, tile, L.n_padded, 0, T, p.o, p.d, vdot(p.d, p.d), L.t_min, b, cand, st);
 #ifdef RT_EXP_PRIMARY2
         scan_primary(geo0, tile, L.n_padded, 0, T, p.o, p.d, vdot(p.d, p.d), L.t_min, b, cand, st);   // cost experiment: changes nothing (strict bound)
@@ -1002,6 +1015,7 @@ RT_DEV void render_queue_body(const Scene& sc, uint32_t* __restrict__ rgba, floa
         if (__ballot(more) == 0ull) break;
 
         bool finished = false;                                   // this lane's path ended in this round
+        st.lap(14);
         if (active) {
             Best b;
             b.t = L.t_max;
@@ -1034,11 +1048,8 @@ RT_DEV void render_queue_body(const Scene& sc, uint32_t* __restrict__ rgba, floa
             for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
             if (lane == 0u && x) atomicAdd(segments + w, x);
         }
-        {   // camera-ray batches traced (scan_primary calls)
-            unsigned long long x = st.v[0];
-            for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
-            if (lane == 0u && x) atomicAdd(segments + 15, x);
-        }
+        for (int w = 0; w < 7; w++)
+            if (lane == 0u) atomicAdd(segments + 9 + w, st.cyc[w]);
 #endif
     }
 }

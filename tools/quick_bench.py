@@ -29,7 +29,7 @@ print(w.device_info(), hs)
 
 
 def sections(c):
-    names = ["scan", "decode", "exact", "hit+scatter", "sky/next", "hand-out", "rest"]
+    names = ["scan", "decode", "exact", "hit+scatter", "sky/add", "hand-out/queue/raygen", "camera-ray filter"]
     tot = sum(c[9:16]) or 1
     return ", ".join(f"{n} {100 * v / tot:.1f}%" for n, v in zip(names, c[9:16]))
 
