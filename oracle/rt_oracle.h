@@ -69,6 +69,17 @@ void or32_pixel_center_ray(const OrCameraF *cam, uint32_t x, uint32_t y, float o
 void or64_miss_color(const double dir[3], double blend, double rgb[3]);
 void or32_miss_color(const float dir[3], float blend, float rgb[3]);
 
+/* One scatter event (Material::scatter library.cu:131-149,175-183 + the book's dielectric): new direction for
+ * incoming direction d at a surface with normal n (facing the ray; front = the ray comes from outside).
+ * `param` is fuzz (clamped to <= 1 as library.cu:144 does) or the index of refraction. */
+void or64_scatter_dir(uint32_t material, double param, const double d[3], const double n[3], int front, uint64_t seed,
+                      uint32_t pixel, uint32_t sample, uint32_t k, uint32_t flags, double out[3]);
+void or32_scatter_dir(uint32_t material, float param, const float d[3], const float n[3], int front, uint64_t seed,
+                      uint32_t pixel, uint32_t sample, uint32_t k, uint32_t flags, float out[3]);
+/* The random unit vector of stream (seed, pixel, sample, k): lib.rs:31-47. */
+void or64_unit_vector(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t k, double out[3]);
+void or32_unit_vector(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t k, float out[3]);
+
 /* Closest hit of every pixel-centre ray: sphere index or -1; optional t, point(3), normal(3) per pixel
  * (Sphere::hit lib.rs:96-125 / library.cu:198-227 under the closest-hit fold lib.rs:127-135 / ray.cu:1-18). */
 void or64_primary_hits(const OrCameraD *cam, const RtSphere *spheres, uint32_t n, double t_min, double t_max,

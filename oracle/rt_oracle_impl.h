@@ -235,6 +235,34 @@ static inline V3 NAME(scatter)(const NAME(Sph) *sp, V3 d, const NAME(Hit) *h, ui
     return NAME(v3)(MADD(par, n.x, perp.x), MADD(par, n.y, perp.y), MADD(par, n.z, perp.z));
 }
 
+/* One scatter event by itself, for known-answer tests: sphere material (tag, fuzz | ior), incoming direction,
+ * surface normal facing the ray, front-face flag, and the stream key (seed, pixel, sample, k). */
+void NAME(scatter_dir)(uint32_t material, REAL param, const REAL d[3], const REAL n[3], int front, uint64_t seed,
+                       uint32_t pixel, uint32_t sample, uint32_t k, uint32_t flags, REAL out[3]) {
+    NAME(Sph) sp;
+    sp.c = NAME(v3)(R(0), R(0), R(0)); sp.r = R(1); sp.rr = R(1);
+    sp.mat = material;
+    sp.albedo = NAME(v3)(R(1), R(1), R(1));
+    float pf = (float)param;
+    if (material == RT_MAT_REFLECT) pf = pf < 1.0f ? pf : 1.0f; /* fuzz clamp, library.cu:144 */
+    sp.param = R(pf);
+    NAME(Hit) h;
+    h.idx = 0; h.t = R(1); h.p = NAME(v3)(R(0), R(0), R(0));
+    h.n = NAME(v3)(n[0], n[1], n[2]);
+    h.front = front;
+    V3 atten;
+    V3 o = NAME(scatter)(&sp, NAME(v3)(d[0], d[1], d[2]), &h, seed, pixel, sample, k, flags, &atten);
+    out[0] = o.x; out[1] = o.y; out[2] = o.z;
+}
+
+/* The unit vector a stream's rejection loop yields (lib.rs:31-47), by itself. */
+void NAME(unit_vector)(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t k, REAL out[3]) {
+    NAME(Rng) g;
+    or_stream_init(&g.state, &g.inc, seed, pixel, sample, k);
+    V3 v = NAME(random_unit_vector)(&g);
+    out[0] = v.x; out[1] = v.y; out[2] = v.z;
+}
+
 /* ray_color (lib.rs:184-206 recursive, ray.cu:22-49 iterative): radiance of one path, counting segments. */
 static inline V3 NAME(ray_color)(const NAME(Sph) *w, uint32_t n, V3 o, V3 d, const RtParams *prm,
                                  uint32_t pixel, uint32_t sample, REAL band, uint64_t *nseg) {

@@ -97,6 +97,12 @@ def lib():
                                   C.c_int, vp, vp, C.POINTER(C.c_uint64)]
         L.or32_render.argtypes = [C.POINTER(OrCameraF), vp, C.c_uint32, vp, C.c_uint32, C.c_uint32,
                                   C.c_int, vp, vp, C.POINTER(C.c_uint64)]
+        L.or64_scatter_dir.argtypes = [C.c_uint32, C.c_double, vp, vp, C.c_int, C.c_uint64, C.c_uint32, C.c_uint32,
+                                       C.c_uint32, C.c_uint32, vp]
+        L.or32_scatter_dir.argtypes = [C.c_uint32, C.c_float, vp, vp, C.c_int, C.c_uint64, C.c_uint32, C.c_uint32,
+                                       C.c_uint32, C.c_uint32, vp]
+        L.or64_unit_vector.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, vp]
+        L.or32_unit_vector.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, vp]
         L.or32_show_random.argtypes = [C.c_uint32, C.c_uint32, C.c_uint64, C.c_int, vp]
         _lib = L
     return _lib
@@ -174,6 +180,21 @@ def render(cam, spheres, params, row0=0, rows=None, threads=None):
     fn(C.byref(cam), _ptr(sp), len(sp), C.addressof(params), row0, rows, threads or default_threads(),
        _ptr(rgba), _ptr(lin), C.byref(seg))
     return rgba, lin, seg.value
+
+
+def scatter_dir(material, param, d, n, front=True, key=(0, 0, 0, 1), flags=0, f64=True):
+    """New direction of one scatter event; key = (seed, pixel, sample, k) of the stream it may draw from."""
+    ft = np.float64 if f64 else np.float32
+    dv, nv, out = np.asarray(d, ft).copy(), np.asarray(n, ft).copy(), np.zeros(3, ft)
+    fn = lib().or64_scatter_dir if f64 else lib().or32_scatter_dir
+    fn(material, param, _ptr(dv), _ptr(nv), int(front), key[0], key[1], key[2], key[3], flags, _ptr(out))
+    return out
+
+
+def unit_vector(key, f64=True):
+    out = np.zeros(3, np.float64 if f64 else np.float32)
+    (lib().or64_unit_vector if f64 else lib().or32_unit_vector)(key[0], key[1], key[2], key[3], _ptr(out))
+    return out
 
 
 def show_random(width, height, seed, norm):

@@ -176,3 +176,139 @@ def test_exact_accumulation_of_a_tiny_negative_run_sum(oracle):
         _, ref, _ = oracle.render(cam, sp, fold)
         assert (ref[..., :3] < 0).any()                       # the case is really exercised
         assert np.abs(lin[..., :3].astype(np.float64) - ref[..., :3]).max() < 1e-6    # a missed carry is off by 1/spp = 0.25
+
+
+# ---------------------------------------------------------------- what "Ray Tracing in One Weekend" pins
+# The reference has no dielectric and no tests; these pin the checker's scatter to the physics the book states
+# (and to the reference's own lines for the mirror law, the fuzz clamp and the near-zero guard).
+
+def _unit(v):
+    v = np.asarray(v, np.float64)
+    return v / np.linalg.norm(v)
+
+
+def test_mirror_law_for_reflect_with_fuzz_zero(oracle):
+    """floatN_helper.cu:124-127: r = d - 2 (d.n) n, normalised (library.cu:146); with fuzz 0 nothing is added:
+    angle of incidence = angle of reflection, r in the plane of d and n, and no draw from any stream."""
+    rng = np.random.default_rng(1)
+    for _ in range(200):
+        n = _unit(rng.normal(size=3))
+        d = rng.normal(size=3) * rng.uniform(0.1, 10)
+        if d @ n > 0:
+            d = -d
+        r = oracle.scatter_dir(2, 0.0, d, n)
+        assert abs(np.linalg.norm(r) - 1.0) < 1e-12
+        assert abs(r @ n + _unit(d) @ n) < 1e-12                  # equal angles, opposite sides
+        assert abs(np.linalg.det(np.stack([_unit(d), n, r]))) < 1e-12   # coplanar
+        for key in ((1, 2, 3, 4), (9, 9, 9, 9)):                  # no dependence on the stream
+            assert np.array_equal(oracle.scatter_dir(2, 0.0, d, n, key=key), r)
+
+
+def test_fuzz_is_clamped_to_one_and_adds_a_unit_vector(oracle):
+    """library.cu:144 clamps fuzz to <= 1; library.cu:147 adds fuzz * random unit vector to the mirror direction."""
+    n = np.array([0.0, 1.0, 0.0])
+    d = np.array([1.0, -1.0, 0.25])
+    mirror = oracle.scatter_dir(2, 0.0, d, n)
+    key = (5, 6, 7, 8)
+    ru = oracle.unit_vector(key)
+    assert abs(np.linalg.norm(ru) - 1.0) < 1e-12
+    for fuzz, eff in ((0.3, 0.3), (1.0, 1.0), (7.0, 1.0)):
+        got = oracle.scatter_dir(2, fuzz, d, n, key=key)
+        assert np.allclose(got, mirror + np.float32(eff).astype(np.float64) * ru, rtol=0, atol=1e-12)
+
+
+def test_snell_law_and_total_internal_reflection(oracle):
+    """Refraction obeys n1 sin(t1) = n2 sin(t2) with the refracted ray in the plane of incidence; the ray is
+    reflected exactly when ri * sin(t1) > 1 (book section 11.2-11.3)."""
+    rng = np.random.default_rng(2)
+    ior = 1.5
+    refr = tir = 0
+    for _ in range(600):
+        n = _unit(rng.normal(size=3))
+        d = _unit(rng.normal(size=3)) * rng.uniform(0.2, 5)
+        if d @ n > 0:
+            d = -d
+        front = bool(rng.integers(0, 2))
+        ri = 1.0 / ior if front else ior
+        cos1 = min(-_unit(d) @ n, 1.0)
+        sin1 = np.sqrt(1.0 - cos1 * cos1)
+        # u_choice is drawn from the stream: look for a key whose draw is above the Schlick reflectance, so that
+        # the ray refracts whenever it can
+        out = None
+        for k in range(1, 40):
+            o = oracle.scatter_dir(3, ior, d, n, front=front, key=(3, 1, 4, k))
+            if o @ n < 0:
+                out = o
+                break
+        if ri * sin1 > 1.0:
+            tir += 1
+            assert out is None                                   # every draw reflects
+            o = oracle.scatter_dir(3, ior, d, n, front=front, key=(3, 1, 4, 1))
+            assert abs(o @ n + _unit(d) @ n) < 1e-12 and abs(np.linalg.norm(o) - 1) < 1e-12
+        elif out is not None:
+            refr += 1
+            sin2 = np.linalg.norm(np.cross(out, -n)) / np.linalg.norm(out)
+            assert abs(ri * sin1 - sin2) < 1e-9, (ri, sin1, sin2)
+            assert abs(np.linalg.norm(out) - 1.0) < 1e-9
+            assert abs(np.linalg.det(np.stack([_unit(d), n, out]))) < 1e-9
+    assert refr > 200 and tir > 50
+
+
+def test_schlick_reflectance(oracle):
+    """Probability of reflection = r0 + (1 - r0)(1 - cos)^5, r0 = ((1 - ri)/(1 + ri))^2: 0.04 for glass (1.5) at
+    normal incidence, -> 1 at grazing incidence.  Measured as the share of streams that reflect."""
+    n = np.array([0.0, 0.0, 1.0])
+
+    def share(d, trials=4000):
+        hits = 0
+        for k in range(trials):
+            o = oracle.scatter_dir(3, 1.5, d, n, front=True, key=(11, k, 0, 1))
+            hits += o @ n > 0
+        return hits / trials
+
+    assert abs(share(np.array([0.0, 0.0, -1.0])) - 0.04) < 0.012            # 3.9 sigma of a binomial(4000, 0.04)
+    theta = np.deg2rad(60.0)
+    want = 0.04 + 0.96 * (1 - np.cos(theta)) ** 5
+    assert abs(share(np.array([np.sin(theta), 0.0, -np.cos(theta)])) - want) < 0.015
+    assert share(np.array([1.0, 0.0, -1e-4])) > 0.995                      # grazing
+
+
+def test_lambertian_direction_and_near_zero_guard(oracle):
+    """Diffuse: normal + random unit vector (library.cu:132, lib.rs:194): within a unit of the normal, cosine-weighted
+    (mean of n.out/|out| = 2/3); a sum within 1e-8 of zero per component is replaced by the normal
+    (floatN_helper.cu:116-119) -- and is not in the CPU crate's mode (lib.rs:194-201 has no guard)."""
+    n = np.array([0.0, 1.0, 0.0])
+    d = np.array([0.3, -1.0, 0.1])
+    cos = []
+    for k in range(3000):
+        key = (21, k, 1, 2)
+        out = oracle.scatter_dir(1, 0.0, d, n, key=key)
+        assert np.allclose(out - n, oracle.unit_vector(key), atol=1e-15)
+        cos.append(out @ n / np.linalg.norm(out))
+    assert abs(np.mean(cos) - 2.0 / 3.0) < 0.02
+    # the guard: pick the stream's own unit vector and use its negative as the normal
+    key = (21, 5, 1, 2)
+    ru = oracle.unit_vector(key, f64=False)
+    out = oracle.scatter_dir(1, 0.0, d.astype(np.float32), -ru, key=key, f64=False)
+    assert np.array_equal(out, -ru)                                        # n + ru == 0 exactly -> the normal
+    out = oracle.scatter_dir(1, 0.0, d.astype(np.float32), -ru, key=key, flags=4, f64=False)
+    assert np.array_equal(out, np.zeros(3, np.float32))                    # lib.rs: no guard
+
+
+def test_unit_vector_sampler_is_uniform_on_the_sphere(oracle):
+    """Rejection in the cube, accept p.p <= 1, normalise (lib.rs:31-47): unit length, zero mean, second moments
+    1/3 on the diagonal and 0 off it, and the third coordinate (cut from the low bits of both generator outputs)
+    uncorrelated with the other two."""
+    v = np.array([oracle.unit_vector((77, p, s, 1)) for p in range(200) for s in range(100)])
+    assert np.allclose(np.linalg.norm(v, axis=1), 1.0, atol=1e-12)
+    m = len(v)
+    assert np.abs(v.mean(axis=0)).max() < 4.0 / np.sqrt(3 * m)
+    cov = v.T @ v / m
+    assert np.abs(cov - np.eye(3) / 3).max() < 0.012
+    # octant counts: 8 equal cells
+    octant = (v[:, 0] > 0) * 4 + (v[:, 1] > 0) * 2 + (v[:, 2] > 0)
+    counts = np.bincount(octant, minlength=8)
+    assert np.abs(counts - m / 8).max() < 5 * np.sqrt(m / 8)
+    # z is uniform on [-1, 1] for a uniform direction (Archimedes): 20 equal bins
+    hist, _ = np.histogram(v[:, 2], bins=20, range=(-1, 1))
+    assert np.abs(hist - m / 20).max() < 5 * np.sqrt(m / 20)

@@ -6,6 +6,10 @@ Kernel (rt_kernels.hip, scan_tile), with T the scene translation, c' = fl(c - T)
   key = fma(g, g, t) + m                               m = r*r(1+2^-17) - |c'|^2 (1-2^-18), rounded up;
   candidate iff sign(key) clear.
 Exact test (checker order):  disc = fma(h, h, a*ncc),  h = d.oc,  ncc = r*r - oc.oc, oc = c - o;  needs disc >= 0.
+Camera rays (scan_primary) share their origin, so t + m is formed once per sphere when the tile is staged,
+  tm = fl(t + m)   with t as above for the camera centre,      key = fma(g, g, tm):
+one rounding moves from the end of the chain to tm.  Every case below checks both forms (any origin can be a
+camera centre).
 Here both are evaluated in numpy with float32 fma emulated through float64 (products of two float32 are
 exact in float64), on random and adversarial ray/sphere pairs."""
 import numpy as np
@@ -42,7 +46,8 @@ def filt(o, d, c, rr, a, T):
     k0 = -((dot(op, op) * f32(1.0 - 2.0 ** -18)).astype(f32))
     t = fma(w[2], cp[2], fma(w[1], cp[1], fma(w[0], cp[0], k0)))
     g = fma(uf[2], cp[2], fma(uf[1], cp[1], fma(uf[0], cp[0], e)))
-    return (fma(g, g, t) + m).astype(f32)
+    tm = (t + m).astype(f32)                       # staged once per sphere for the camera centre (geo0.w)
+    return (fma(g, g, t) + m).astype(f32), fma(g, g, tm)
 
 
 def check(o, d, c, r, label, T=(0.0, 0.0, 0.0)):
@@ -51,11 +56,12 @@ def check(o, d, c, r, label, T=(0.0, 0.0, 0.0)):
     c = [x.astype(f32) for x in c]
     rr = (r.astype(f32) * r.astype(f32)).astype(f32)
     oc, a, h, ncc, disc = terms(o, d, c, rr)
-    q = filt(o, d, c, rr, a, [f32(x) for x in T])
+    q, q5 = filt(o, d, c, rr, a, [f32(x) for x in T])
     accepted = disc >= 0
-    dropped = accepted & np.signbit(q)
     assert accepted.sum() > 0, label
-    assert not dropped.any(), f"{label}: {dropped.sum()} exact-test candidates dropped by the filter"
+    for form, key in (("scan_tile", q), ("scan_primary", q5)):
+        dropped = accepted & np.signbit(key)
+        assert not dropped.any(), f"{label}: {dropped.sum()} exact-test candidates dropped by the {form} filter"
     return accepted.mean()
 
 
@@ -126,3 +132,25 @@ def test_extreme_scales():
         d = (aim - o) / np.linalg.norm(aim - o, axis=0) * dscale
         check(list(o), list(d), list(c), r, f"scale {scale} dir {dscale}")
         check(list(o + 1000.0 * scale), list(d), list(c + 1000.0 * scale), r, f"scale {scale} dir {dscale}, far from T")
+
+
+def test_camera_inside_spheres_on_surfaces_and_far_from_the_translation():
+    """The cases where the one moved rounding of the camera-ray form could matter: the camera centre inside a
+    sphere (every ray hits), exactly on a surface, and a scene whose spheres lie 1e3 .. 1e5 from the translation T
+    (large |c'|: large cancelling terms in t + m)."""
+    rng = np.random.default_rng(5)
+    n = 1_000_000
+    c = rng.uniform(-10, 10, (3, n)); r = rng.uniform(0.5, 30.0, n)
+    o = c + unit(rng, n) * r * rng.uniform(0.0, 0.999, n)                   # inside
+    assert check(list(o), list(unit(rng, n) * rng.uniform(0.1, 4.0, n)), list(c), r, "camera inside") == 1.0
+    o = c + unit(rng, n) * r                                                  # on the surface, to rounding
+    check(list(o), list(unit(rng, n)), list(c), r, "camera on a surface")
+    for far in (1e3, 1e4, 1e5):
+        c = rng.uniform(-20, 20, (3, n)) + far * unit(rng, 1)
+        r = rng.uniform(0.05, 2.0, n)
+        o = c + unit(rng, n) * r * rng.uniform(1.0, 40.0, n)
+        aim = c + unit(rng, n) * r * rng.uniform(0.9, 1.1, n)
+        d = (aim - o) * rng.uniform(0.2, 3.0, n)
+        check(list(o), list(d), list(c), r, f"centres {far:g} from T")
+        # and with T where the kernel would put it (the median of the centres): the same pairs, small |c'|
+        check(list(o), list(d), list(c), r, f"centres {far:g} from the origin, T at their median", T=tuple(np.median(c, axis=1)))
