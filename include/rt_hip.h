@@ -134,8 +134,8 @@ int rt_show_random(rt_ctx *ctx, uint32_t width, uint32_t height, uint64_t seed, 
 
 /* Milliseconds the last render kernel took on the GPU (hipEvent pair around the launch). */
 float rt_last_kernel_ms(const rt_ctx *ctx);
-/* Name of the kernel the last render launched (rt_render, rt_render_stream, rt_render_queue or
- * rt_render_queue_stream), for profiles. */
+/* Name of the kernel the last render launched (rt_render, rt_render_stream, rt_render_queue,
+ * rt_render_queue_stream, rt_render_queue_fold or rt_render_queue_stream_fold), for profiles. */
 const char *rt_last_kernel_name(const rt_ctx *ctx);
 
 /* Diagnostic: the 16 64-bit counters of the last render that asked for rays_out.  out[0] = ray segments;

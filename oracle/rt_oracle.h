@@ -99,6 +99,16 @@ void or32_render(const OrCameraF *cam, const RtSphere *spheres, uint32_t n, cons
                  uint32_t row0, uint32_t rows, int threads,
                  uint8_t *rgba, float *linear, uint64_t *segments);
 
+/* The same, with an optional per-pixel signature (rows*W words): a hash of the sphere indices the pixel's paths
+ * hit, segment by segment (-1 = sky).  Two renders of one pixel in different precisions followed the same paths
+ * exactly when their signatures agree. */
+void or64_render_sig(const OrCameraD *cam, const RtSphere *spheres, uint32_t n, const RtParams *params,
+                     uint32_t row0, uint32_t rows, int threads,
+                     uint8_t *rgba, double *linear, uint64_t *segments, uint64_t *path_sig);
+void or32_render_sig(const OrCameraF *cam, const RtSphere *spheres, uint32_t n, const RtParams *params,
+                     uint32_t row0, uint32_t rows, int threads,
+                     uint8_t *rgba, float *linear, uint64_t *segments, uint64_t *path_sig);
+
 /* RNG debug views of ray.cu:114-118: per pixel, 3 uniform floats (norm = 0) or a random unit vector (norm = 1),
  * from stream (seed, pixel, 0, 0), quantised by to_pixel (ray.cu:81-89). */
 void or32_show_random(uint32_t width, uint32_t height, uint64_t seed, int norm, uint8_t *rgba);

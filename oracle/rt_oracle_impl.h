@@ -265,7 +265,7 @@ void NAME(unit_vector)(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t 
 
 /* ray_color (lib.rs:184-206 recursive, ray.cu:22-49 iterative): radiance of one path, counting segments. */
 static inline V3 NAME(ray_color)(const NAME(Sph) *w, uint32_t n, V3 o, V3 d, const RtParams *prm,
-                                 uint32_t pixel, uint32_t sample, REAL band, uint64_t *nseg) {
+                                 uint32_t pixel, uint32_t sample, REAL band, uint64_t *nseg, uint64_t *sig) {
     const uint32_t flags = prm->flags;
     const REAL t_min = R(prm->t_min), t_max = R(prm->t_max);
     V3 thr = NAME(v3)(R(1), R(1), R(1));
@@ -274,6 +274,7 @@ static inline V3 NAME(ray_color)(const NAME(Sph) *w, uint32_t n, V3 o, V3 d, con
         if (seg == prm->max_depth) return NAME(v3)(R(0), R(0), R(0)); /* lib.rs:190-192, ray.cu:30-32 */
         (*nseg)++;
         NAME(Hit) h = NAME(closest_hit)(w, n, o, d, t_min, t_max, flags);
+        if (sig) *sig = (*sig ^ (uint64_t)(uint32_t)(h.idx + 2)) * 0x100000001B3ULL; /* FNV-1a over the hit indices */
         if (h.idx >= 0) {
             V3 atten;
             V3 nd = NAME(scatter)(&w[h.idx], d, &h, prm->seed, pixel, sample, seg + 1, flags, &atten);
@@ -343,6 +344,7 @@ typedef struct {
     uint8_t *rgba;
     REAL *linear;
     uint64_t segments;
+    uint64_t *sig; /* optional, per pixel: hash of the sphere indices its paths hit, in order (-1 = sky) */
     /* primary-hit mode */
     int hits_mode;
     REAL t_min, t_max;
@@ -382,6 +384,7 @@ static void NAME(render_row)(NAME(Job) *jb, uint32_t lr) {
         V3 total = NAME(v3)(R(0), R(0), R(0));
         const uint32_t chunk = (prm->sample_chunk && prm->sample_chunk < spp) ? prm->sample_chunk : 0;
         int64_t fx = 0, fy = 0, fz = 0;
+        uint64_t sig = 0xcbf29ce484222325ULL;
         for (uint32_t s = 0; s < spp; s++) {
             REAL si, sj;
             if (prm->flags & RT_FLAG_SAMPLER_GRID) { /* ray.cu:59-60 */
@@ -396,7 +399,7 @@ static void NAME(render_row)(NAME(Job) *jb, uint32_t lr) {
             }
             V3 o, d;
             NAME(make_ray)(cam, x, y, si, sj, &o, &d);
-            V3 c = NAME(ray_color)(jb->w, jb->n, o, d, prm, pixel, s, band, &nseg);
+            V3 c = NAME(ray_color)(jb->w, jb->n, o, d, prm, pixel, s, band, &nseg, jb->sig ? &sig : NULL);
             total = NAME(add)(total, c); /* lib.rs:228-231, ray.cu:126 */
             if (chunk && ((s + 1) % chunk == 0 || s + 1 == spp)) { /* end of a run: exact accumulation */
                 fx += NAME(to_fixed)(total.x); fy += NAME(to_fixed)(total.y); fz += NAME(to_fixed)(total.z);
@@ -406,6 +409,7 @@ static void NAME(render_row)(NAME(Job) *jb, uint32_t lr) {
         V3 mean = NAME(v3)(total.x / R(spp), total.y / R(spp), total.z / R(spp));
         if (chunk) mean = NAME(v3)(NAME(fixed_mean)(fx, spp), NAME(fixed_mean)(fy, spp), NAME(fixed_mean)(fz, spp));
         size_t k = (size_t)lr * W + x;
+        if (jb->sig) jb->sig[k] = sig;
         if (jb->rgba) {
             jb->rgba[4 * k + 0] = NAME(quant)(mean.x, prm->flags);
             jb->rgba[4 * k + 1] = NAME(quant)(mean.y, prm->flags);
@@ -458,17 +462,23 @@ void NAME(primary_hits)(const CAM *cam, const RtSphere *spheres, uint32_t n, REA
     free(w);
 }
 
-void NAME(render)(const CAM *cam, const RtSphere *spheres, uint32_t n, const RtParams *params,
-                  uint32_t row0, uint32_t rows, int threads,
-                  uint8_t *rgba, REAL *linear, uint64_t *segments) {
+void NAME(render_sig)(const CAM *cam, const RtSphere *spheres, uint32_t n, const RtParams *params,
+                      uint32_t row0, uint32_t rows, int threads,
+                      uint8_t *rgba, REAL *linear, uint64_t *segments, uint64_t *path_sig) {
     NAME(Job) jb;
     memset(&jb, 0, sizeof jb);
     NAME(Sph) *w = NAME(convert_scene)(spheres, n);
     jb.cam = cam; jb.w = w; jb.n = n; jb.prm = params; jb.row0 = row0; jb.rows = rows;
-    jb.rgba = rgba; jb.linear = linear;
+    jb.rgba = rgba; jb.linear = linear; jb.sig = path_sig;
     NAME(run_job)(&jb, threads);
     if (segments) *segments = jb.segments;
     free(w);
+}
+
+void NAME(render)(const CAM *cam, const RtSphere *spheres, uint32_t n, const RtParams *params,
+                  uint32_t row0, uint32_t rows, int threads,
+                  uint8_t *rgba, REAL *linear, uint64_t *segments) {
+    NAME(render_sig)(cam, spheres, n, params, row0, rows, threads, rgba, linear, segments, NULL);
 }
 
 #undef REAL

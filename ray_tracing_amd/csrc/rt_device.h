@@ -33,6 +33,7 @@ typedef struct RtLaunch {
     uint32_t chunk;            // samples per work item (= samples_per_pixel when n_chunks == 1)
     uint32_t n_chunks;         // ceil(samples_per_pixel / chunk); 1 = the reference's fp32 fold
     float    translate[3];     // T of the scan filter: component-wise median of the sphere centres
+    uint32_t fold;             // queue kernels: 1 = finished samples go to the workspace and are added in sample order (fp32 fold)
 } RtLaunch;
 
 // Launch-wide counter block of the render kernels, device memory, cleared before every launch: sixteen 64-bit

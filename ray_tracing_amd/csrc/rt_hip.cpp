@@ -39,7 +39,7 @@ struct rt_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipModule_t module = nullptr;
-    hipFunction_t f_render = nullptr, f_render_queue = nullptr, f_render_stream = nullptr, f_render_queue_stream = nullptr, f_hits = nullptr, f_random = nullptr, f_assemble = nullptr;
+    hipFunction_t f_render = nullptr, f_render_queue = nullptr, f_render_queue_fold = nullptr, f_render_queue_stream_fold = nullptr, f_render_stream = nullptr, f_render_queue_stream = nullptr, f_hits = nullptr, f_random = nullptr, f_assemble = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     void *d_geom = nullptr, *d_exact = nullptr, *d_shade = nullptr, *d_mat = nullptr;
     float translate[3] = {0.0f, 0.0f, 0.0f};
@@ -53,6 +53,8 @@ struct rt_ctx {
     uint32_t dbg_unit_w = 0, dbg_unit_h = 0;
     bool dbg_no_queue = false;
     size_t cap_rgba = 0, cap_linear = 0, cap_hits = 0;
+    void* d_fold = nullptr;             // fold-order workspace of the queue kernels: finished samples until their unit is complete
+    size_t cap_fold = 0;
     // multi-GPU gather: this context is rank `rank` of `world`
     ncclComm_t comm = nullptr;
     uint32_t world = 1, rank = 0;
@@ -103,11 +105,13 @@ int ensure(rt_ctx* c, void** p, size_t* cap, size_t bytes) {
 int load_image(rt_ctx* c, const void* image) {
     hipModule_t m = nullptr;
     RT_HIP(c, hipModuleLoadData(&m, image));
-    hipFunction_t fr, fq, fs, fqs, fh, fx, fa;
+    hipFunction_t fr, fq, fs, fqs, fh, fx, fa, fqf, fqsf;
     hipError_t e;
     if ((e = hipModuleGetFunction(&fr, m, "rt_render")) != hipSuccess ||
         (e = hipModuleGetFunction(&fq, m, "rt_render_queue")) != hipSuccess ||
         (e = hipModuleGetFunction(&fqs, m, "rt_render_queue_stream")) != hipSuccess ||
+        (e = hipModuleGetFunction(&fqf, m, "rt_render_queue_fold")) != hipSuccess ||
+        (e = hipModuleGetFunction(&fqsf, m, "rt_render_queue_stream_fold")) != hipSuccess ||
         (e = hipModuleGetFunction(&fs, m, "rt_render_stream")) != hipSuccess ||
         (e = hipModuleGetFunction(&fh, m, "rt_primary_hits")) != hipSuccess ||
         (e = hipModuleGetFunction(&fx, m, "rt_show_random")) != hipSuccess ||
@@ -146,7 +150,7 @@ int load_image(rt_ctx* c, const void* image) {
     c->counter_need = need;
     if (c->module) (void)hipModuleUnload(c->module);
     c->module = m;
-    c->f_render = fr; c->f_render_queue = fq; c->f_render_queue_stream = fqs; c->f_render_stream = fs; c->f_hits = fh; c->f_random = fx; c->f_assemble = fa;
+    c->f_render_queue_fold = fqf; c->f_render_queue_stream_fold = fqsf; c->f_render = fr; c->f_render_queue = fq; c->f_render_queue_stream = fqs; c->f_render_stream = fs; c->f_hits = fh; c->f_random = fx; c->f_assemble = fa;
     return 0;
 }
 
@@ -173,8 +177,16 @@ int check_render(rt_ctx* c, const RtParams* p) {
     return 0;
 }
 
+// can this launch run on the camera-ray-batch kernels?  (every sample its own work item)
+bool queue_kernel_fits(const rt_ctx* c, uint32_t spp) {
+    return !c->dbg_no_queue && spp >= 2u && (uint64_t)64u * spp < (1ull << 31) &&
+           c->n_padded <= 65536u;                                // a queued ray names the sphere it left in 16 bits
+}
+
+// fold_queue: sample_chunk = 0 (the reference's fp32 fold) may run on the camera-ray-batch kernels with a workspace
+// for the finished samples; false keeps it on the one-lane-per-pixel kernel, which needs none.
 RtLaunch make_launch(const rt_ctx* c, const RtCamera* cam, const RtParams* p, uint32_t row_base,
-                     uint32_t rows_local, uint32_t tile_rows, uint32_t tile_stride_rows) {
+                     uint32_t rows_local, uint32_t tile_rows, uint32_t tile_stride_rows, bool fold_queue = false) {
     RtLaunch L;
     std::memset(&L, 0, sizeof L);
     L.n_spheres = c->n_spheres;
@@ -197,10 +209,12 @@ RtLaunch make_launch(const rt_ctx* c, const RtCamera* cam, const RtParams* p, ui
     L.n_wave_tiles = L.tiles_x * ((rows_local + 7u) / 8u);
     // work decomposition of the render kernels
     const uint32_t spp = p->samples_per_pixel ? p->samples_per_pixel : 1u;
-    if (p->sample_chunk == 0 || p->sample_chunk >= spp) {
+    const bool fold = p->sample_chunk == 0 || p->sample_chunk >= spp;
+    if (fold && !(fold_queue && queue_kernel_fits(c, spp))) {
         L.chunk = spp; L.n_chunks = 1; L.unit_w = L.unit_h = 8;         // one lane per pixel, fp32 fold
     } else {
-        L.chunk = p->sample_chunk;
+        L.fold = fold ? 1u : 0u;                                        // samples traced in any order, added in sample order
+        L.chunk = fold ? 1u : p->sample_chunk;
         L.n_chunks = (spp + L.chunk - 1u) / L.chunk;
         // Unit shape only affects scheduling (the sums are exact).  A wavefront has two units open at a time, so
         // small units cost nothing inside the wavefront, and they shorten the end of the launch, when the last
@@ -215,6 +229,12 @@ RtLaunch make_launch(const rt_ctx* c, const RtCamera* cam, const RtParams* p, ui
             if (L.unit_h < L.unit_w && height_ok(2u * L.unit_h)) L.unit_h *= 2u; else L.unit_w *= 2u;
         }
         if (c->dbg_unit_w && height_ok(c->dbg_unit_h)) { L.unit_w = c->dbg_unit_w; L.unit_h = c->dbg_unit_h; }   // rt_debug_schedule
+        // fold-order workspace: 2 units x P pixels x spp colours of 16 bytes per wavefront, at most 32 wavefronts per
+        // compute unit resident; beyond 8 GiB the fold stays on the one-lane-per-pixel kernel
+        const uint64_t fold_bytes = (uint64_t)(c->compute_units > 0 ? c->compute_units : 256) * 32u * 2u * L.unit_w * L.unit_h * spp * 16u;
+        if (L.fold && fold_bytes > (8ull << 30)) {
+            L.fold = 0u; L.chunk = spp; L.n_chunks = 1; L.unit_w = L.unit_h = 8;
+        }
     }
     for (int k = 0; k < 3; k++) L.translate[k] = c->translate[k];
     for (L.unit_shift = 0; (1u << L.unit_shift) < L.unit_w; L.unit_shift++) {}
@@ -241,19 +261,25 @@ size_t lds_bytes(const rt_ctx* c, unsigned block, unsigned unit_pixels) {
 // `counters`: RT_COUNTER_BYTES of device memory for the launch-wide counters (the context's own block, or the
 // library's static array).  Allocates nothing.
 int launch_render(rt_ctx* c, const RtCamera* cam, const RtParams* p, RtLaunch L, void* d_rgba, void* d_linear,
-                  uint64_t* rays_out, void* counters) {
+                  uint64_t* rays_out, void* counters, bool fold_workspace = true) {
     unsigned grid, block;
     launch_geometry(p, L.n_units, &grid, &block);
     const unsigned waves = block / 64u, P = L.unit_w * L.unit_h;
     hipFunction_t f;
     unsigned lds;
     if ((uint64_t)P * L.n_chunks >= (1ull << 31)) return fail(c, RT_ERR_INVALID, "too many work items per pixel unit (samples_per_pixel / sample_chunk too large)");
-    if (L.n_chunks > 1 && L.chunk == 1 && !c->dbg_no_queue && (uint64_t)P * L.samples_per_pixel < (1ull << 31) &&
-        c->n_padded <= 65536u) {                                 // a queued ray names the sphere it left in 16 bits
+    const bool queue = L.n_chunks > 1 && L.chunk == 1 && queue_kernel_fits(c, L.samples_per_pixel);
+    if (L.fold && !queue) return fail(c, RT_ERR_INVALID, "internal: fold-order launch prepared for a kernel that cannot run it");
+    if (queue) {
         // every sample its own item: camera rays traced in batches, bounce rays from a queue
         const bool one_tile = c->n_padded <= RT_TILE_SPHERES;
-        f = one_tile ? c->f_render_queue : c->f_render_queue_stream;
-        c->last_kernel = one_tile ? "rt_render_queue" : "rt_render_queue_stream";
+        if (L.fold) {
+            f = one_tile ? c->f_render_queue_fold : c->f_render_queue_stream_fold;
+            c->last_kernel = one_tile ? "rt_render_queue_fold" : "rt_render_queue_stream_fold";
+        } else {
+            f = one_tile ? c->f_render_queue : c->f_render_queue_stream;
+            c->last_kernel = one_tile ? "rt_render_queue" : "rt_render_queue_stream";
+        }
         lds = (one_tile ? c->n_padded : RT_Q_STREAM_TILE) * 32u + waves * (RT_Q_CAND_CAP * 128u + 48u * P + RT_Q_WORDS * 256u);
     } else {
         f = (c->n_padded <= RT_TILE_SPHERES) ? c->f_render : c->f_render_stream;
@@ -267,12 +293,21 @@ int launch_render(rt_ctx* c, const RtCamera* cam, const RtParams* p, RtLaunch L,
     if (resident < 1) return fail(c, RT_ERR_INVALID, "render kernel does not fit a compute unit with this block_dim and scene");
     const unsigned fill = (unsigned)resident * (unsigned)(c->compute_units > 0 ? c->compute_units : 1);
     if (grid > fill) grid = fill;
+    // fold-order workspace: per wavefront of the grid, two open units x P pixels x samples_per_pixel colours
+    void* d_fold = nullptr;
+    if (L.fold) {
+        const size_t need = (size_t)grid * waves * 2u * P * L.samples_per_pixel * 16u;
+        if (!fold_workspace) return fail(c, RT_ERR_INVALID, "internal: fold-order launch without a workspace");
+        int rc = ensure(c, &c->d_fold, &c->cap_fold, need);
+        if (rc) return rc;
+        d_fold = c->d_fold;
+    }
     // counter block: [0] path segments (+ diagnostics in [1..7]), 64-bit each; byte 64: the unit counter
     void* d_count = rays_out ? counters : nullptr;
     void* d_work = static_cast<char*>(counters) + 64;
     RT_HIP(c, hipMemsetAsync(counters, 0, c->counter_need, c->stream));
     RtCamera cam_copy = *cam;
-    void* args[] = {&c->d_geom, &c->d_exact, &c->d_shade, &c->d_mat, &d_rgba, &d_linear, &d_count, &d_work, &cam_copy, &L};
+    void* args[] = {&c->d_geom, &c->d_exact, &c->d_shade, &c->d_mat, &d_rgba, &d_linear, &d_count, &d_work, &d_fold, &cam_copy, &L};
     RT_HIP(c, hipEventRecord(c->ev0, c->stream));
     if (grid > 0)
         RT_HIP(c, hipModuleLaunchKernel(f, grid, 1, 1, block, 1, 1, lds, c->stream, args, nullptr));
@@ -423,7 +458,7 @@ void rt_destroy(rt_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->comm && rccl()->CommDestroy) (void)rccl()->CommDestroy(c->comm);
-    void* bufs[] = {c->d_geom, c->d_exact, c->d_shade, c->d_mat, c->d_rgba, c->d_linear, c->d_hits, c->d_counter, c->d_tiles, c->d_frame, c->d_status};
+    void* bufs[] = {c->d_geom, c->d_exact, c->d_shade, c->d_mat, c->d_rgba, c->d_linear, c->d_hits, c->d_counter, c->d_tiles, c->d_frame, c->d_status, c->d_fold};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -525,7 +560,7 @@ int rt_render_rows(rt_ctx* c, const RtCamera* cam, const RtParams* p, uint32_t r
     size_t px = (size_t)rows * cam->image_width;
     if ((rc = ensure(c, &c->d_rgba, &c->cap_rgba, px * 4))) return rc;
     if (linear_out && (rc = ensure(c, &c->d_linear, &c->cap_linear, px * 16))) return rc;
-    RtLaunch L = make_launch(c, cam, p, row0, rows, rows, rows);
+    RtLaunch L = make_launch(c, cam, p, row0, rows, rows, rows, true);
     if ((rc = launch_render(c, cam, p, L, c->d_rgba, linear_out ? c->d_linear : nullptr, rays_out, c->d_counter))) return rc;
     RT_HIP(c, hipMemcpy(rgba_out, c->d_rgba, px * 4, hipMemcpyDeviceToHost));      // memcpy_dtoh, ray_tracing.rs:206-208
     if (linear_out) RT_HIP(c, hipMemcpy(linear_out, c->d_linear, px * 16, hipMemcpyDeviceToHost));
@@ -545,8 +580,10 @@ static int render_tiles_into(rt_ctx* c, const RtCamera* cam, const RtParams* p, 
     if ((uint64_t)tile_stride * tile_rows >= (1ull << 31)) return fail(c, RT_ERR_INVALID, "tile_stride * tile_rows must be below 2^31");
     RT_HIP(c, hipSetDevice(c->device));
     if (n_tiles == 0) { if (rays_out) *rays_out = 0; c->last_ms = 0.0f; return 0; }
-    RtLaunch L = make_launch(c, cam, p, first_tile * tile_rows, n_tiles * tile_rows, tile_rows, tile_stride * tile_rows);
-    return launch_render(c, cam, p, L, d_rgba, d_linear, rays_out, counters);
+    // the allocation-free entry point keeps the fold on the kernel that needs no workspace
+    const bool may_allocate = counters == c->d_counter;
+    RtLaunch L = make_launch(c, cam, p, first_tile * tile_rows, n_tiles * tile_rows, tile_rows, tile_stride * tile_rows, may_allocate);
+    return launch_render(c, cam, p, L, d_rgba, d_linear, rays_out, counters, may_allocate);
 }
 
 int rt_render_tiles_device(rt_ctx* c, const RtCamera* cam, const RtParams* p, uint32_t tile_rows,
@@ -697,7 +734,7 @@ int rt_render_frame_sharded(rt_ctx* c, const RtCamera* cam, const RtParams* p, u
         if (rank == 0 && (r = ensure(c, &c->d_frame, &c->cap_frame, frame_bytes))) return r;
         const uint32_t mine = tiles_of_rank(H, tile_rows, rank, world);
         if (mine) {
-            RtLaunch L = make_launch(c, cam, p, rank * tile_rows, mine * tile_rows, tile_rows, world * tile_rows);
+            RtLaunch L = make_launch(c, cam, p, rank * tile_rows, mine * tile_rows, tile_rows, world * tile_rows, true);
             if ((r = launch_render(c, cam, p, L, c->d_tiles, nullptr, &rays, c->d_counter))) return r;
         }
         return 0;

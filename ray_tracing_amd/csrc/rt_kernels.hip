@@ -1,8 +1,9 @@
 // rt_kernels.hip -- gfx950 code object of the path tracer: the sphere list streamed from LDS (every lane
 // of a wavefront reads the same float4 per step), counter-based PCG32 streams, fp32 register
-// accumulation, gamma + RGBA8 store.  Four render kernels share the code below:
+// accumulation, gamma + RGBA8 store.  Six render kernels share the code below:
 //   rt_render_queue         every sample its own work item, scene within one LDS tile (the fast path)
 //   rt_render_queue_stream  the same for longer sphere lists, streamed tile by tile
+//   rt_render_queue_fold, rt_render_queue_stream_fold   the same two, adding each pixel's samples in sample order
 //   rt_render               work items of `chunk` samples, or one lane per pixel in the reference's fold order
 //   rt_render_stream        the same for longer sphere lists
 // Built with
@@ -542,14 +543,29 @@ RT_DEV Slot open_unit(const RtLaunch& L, uint32_t unit, uint32_t n_items) {
 }
 
 // lanes 0..P-1 finish one pixel of the unit each (mean, gamma, RGBA8) and clear its accumulators
+// `fold` (fold-order mode of the queue kernels): the unit's finished samples, [P][samples_per_pixel] colours in
+// this wavefront's workspace; they are added here in sample order in fp32, the reference's fold (ray.cu:123-129,
+// lib.rs:228-231), whatever order the lanes finished them in.
 RT_DEV void write_unit(const RtLaunch& L, const Slot& u, unsigned long long* acc, uint32_t lane, bool exact_sum,
-                       uint32_t* __restrict__ rgba, float4* __restrict__ linear) {
+                       uint32_t* __restrict__ rgba, float4* __restrict__ linear, const float4* fold = nullptr) {
     const uint32_t P = L.unit_w * L.unit_h;
+    if (fold) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   // the lanes' stores of the samples are visible
     if (lane < P) {
         const uint32_t dx = lane & (L.unit_w - 1u), dy = lane >> L.unit_shift;
         const uint32_t x = u.x0 + dx, ly = u.ly0 + dy, y = u.y0 + dy;
         V3 mean;
-        if (exact_sum) {
+        if (fold) {
+            V3 total = v3(0.0f, 0.0f, 0.0f);
+            const uint32_t n = L.max_depth > 0u ? L.samples_per_pixel : 0u;
+            const float4* mine = fold + (size_t)lane * L.samples_per_pixel;
+            if (x < L.width && ly < L.rows_local && y < L.height)
+                for (uint32_t s = 0u; s < n; s++) {
+                    const float4 c = mine[s];
+                    total = vadd(total, v3(c.x, c.y, c.z));      // ray.cu:126, lib.rs:230
+                }
+            const float fs = (float)L.samples_per_pixel;         // ray.cu:129, lib.rs:231
+            mean = v3(total.x / fs, total.y / fs, total.z / fs);
+        } else if (exact_sum) {
             mean = v3(fixed_mean((long long)acc[lane], L.samples_per_pixel),
                       fixed_mean((long long)acc[P + lane], L.samples_per_pixel),
                       fixed_mean((long long)acc[2u * P + lane], L.samples_per_pixel));
@@ -572,7 +588,7 @@ RT_DEV void render_body(const Scene& sc, uint32_t* __restrict__ rgba, float4* __
                         unsigned long long* __restrict__ segments, uint32_t* __restrict__ work,
                         const RtCamera& cam, const RtLaunch& L) {
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform: kept in a scalar register
     const uint64_t seed = ((uint64_t)L.seed_hi << 32) | L.seed_lo;
     const uint32_t flags = L.flags;
     const uint32_t P = L.unit_w * L.unit_h;
@@ -824,11 +840,19 @@ RT_DEV float band_of(const RtLaunch& L, uint32_t x) {              // lib.rs:225
     return 0.1f + 0.2f * (float)(x / (gi ? gi : 1u));
 }
 
-// one finished sample -> the pixel's fixed-point accumulators (acc = the unit's block, pix = pixel of the unit)
-RT_DEV void add_sample(unsigned long long* acc, uint32_t P, uint32_t pix, V3 color) {
-    atomicAdd(acc + pix, (unsigned long long)to_fixed(color.x));
-    atomicAdd(acc + P + pix, (unsigned long long)to_fixed(color.y));
-    atomicAdd(acc + 2u * P + pix, (unsigned long long)to_fixed(color.z));
+// One finished sample.  acc = the wavefront's accumulators, pixslot = pixel of the unit (+ 3P for slot 1).
+// Exact mode: added to the pixel's fixed-point accumulators.  Fold-order mode (fold != NULL): stored at
+// [slot][pixel][sample] of the wavefront's workspace, to be added in sample order when the unit is complete.
+RT_DEV void add_sample(unsigned long long* acc, uint32_t P, uint32_t pixslot, uint32_t s, uint32_t spp, V3 color, float4* fold) {
+    if (fold) {
+        const uint32_t slot = pixslot >= 3u * P ? 1u : 0u;
+        const uint32_t pix = pixslot - slot * 3u * P;
+        fold[((size_t)slot * P + pix) * spp + s] = make_float4(color.x, color.y, color.z, 0.0f);
+        return;
+    }
+    atomicAdd(acc + pixslot, (unsigned long long)to_fixed(color.x));
+    atomicAdd(acc + P + pixslot, (unsigned long long)to_fixed(color.y));
+    atomicAdd(acc + 2u * P + pixslot, (unsigned long long)to_fixed(color.z));
 }
 
 // Queue entry j becomes the lane's path: the ray that left the camera ray's hit, one segment done.
@@ -875,7 +899,7 @@ RT_DEV uint32_t queue_rays(uint32_t* q, bool cont, const Path& p, uint32_t s, ui
 // image) are counted in `completed`; the others leave a ray in the queue, packed from slot 0 (`queued`).
 RT_DEV void primary_batch(const Scene& sc, const Tile& tile, const float4* __restrict__ geo0, const RtCamera& cam,
                           const RtLaunch& L, uint64_t seed, V3 T, const Slot& u, uint32_t slot, uint32_t first,
-                          uint32_t n_samp, unsigned long long* acc, uint32_t* q, Cand& cand,
+                          uint32_t n_samp, unsigned long long* acc, float4* fold, uint32_t* q, Cand& cand,
                           uint32_t& queued, uint32_t& completed, uint32_t& nseg, Stats& st) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t P = L.unit_w * L.unit_h;
@@ -908,7 +932,7 @@ RT_DEV void primary_batch(const Scene& sc, const Tile& tile, const float4* __res
         sphere = (uint32_t)b.idx;
         V3 color;
         if (shade_segment(sc, L, seed, b, pixel, s, band, p, color, st)) {
-            add_sample(acc, P, pix, color);
+            add_sample(acc, P, pix + (slot ? 3u * P : 0u), s, L.samples_per_pixel, color, fold);
             done = true;
         } else {
             cont = true;
@@ -918,11 +942,12 @@ RT_DEV void primary_batch(const Scene& sc, const Tile& tile, const float4* __res
     completed = (uint32_t)__popcll(__ballot(done));
 }
 
+template <bool FOLD>
 RT_DEV void render_queue_body(const Scene& sc, uint32_t* __restrict__ rgba, float4* __restrict__ linear,
                               unsigned long long* __restrict__ segments, uint32_t* __restrict__ work,
-                              const RtCamera& cam, const RtLaunch& L) {
+                              float4* __restrict__ fold_all, const RtCamera& cam, const RtLaunch& L) {
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform: kept in a scalar register
     const uint64_t seed = ((uint64_t)L.seed_hi << 32) | L.seed_lo;
     const uint32_t flags = L.flags;
     const uint32_t P = L.unit_w * L.unit_h;
@@ -940,6 +965,9 @@ RT_DEV void render_queue_body(const Scene& sc, uint32_t* __restrict__ rgba, floa
     unsigned long long* accum = reinterpret_cast<unsigned long long*>(mine + RT_Q_CAND_CAP * 128u);
     uint32_t* q = reinterpret_cast<uint32_t*>(mine + RT_Q_CAND_CAP * 128u + 48u * P);
     for (uint32_t k = lane; k < 6u * P; k += 64u) accum[k] = 0ull;
+    // fold-order mode: this wavefront's [2 slots][P][samples_per_pixel] colours in the launch's workspace
+    float4* fold = FOLD ? fold_all + (size_t)(blockIdx.x * (blockDim.x >> 6) + wave) * (2u * P * (size_t)L.samples_per_pixel) : nullptr;
+    const float4* fold1 = FOLD ? fold + (size_t)P * L.samples_per_pixel : nullptr;
     {   // stage the spheres; geo0.w = t + m with the operations of scan_tile for the camera centre as origin
         const V3 op = vsub(ld3(cam.center), T);
         const V3 w = v3(2.0f * op.x, 2.0f * op.y, 2.0f * op.z);
@@ -972,8 +1000,8 @@ RT_DEV void render_queue_body(const Scene& sc, uint32_t* __restrict__ rgba, floa
 
     for (;;) {
         // completed units: write their pixels, free the slot
-        if (u0.open && u0.left == 0u) { write_unit(L, u0, accum, lane, true, rgba, linear); u0.open = false; }
-        if (u1.open && u1.left == 0u) { write_unit(L, u1, accum + 3u * P, lane, true, rgba, linear); u1.open = false; }
+        if (u0.open && u0.left == 0u) { write_unit(L, u0, accum, lane, true, rgba, linear, fold); u0.open = false; }
+        if (u1.open && u1.left == 0u) { write_unit(L, u1, accum + 3u * P, lane, true, rgba, linear, fold1); u1.open = false; }
 
         // lanes without a path take queued rays; an empty queue is refilled from the next camera rays
         for (;;) {
@@ -981,8 +1009,8 @@ RT_DEV void render_queue_body(const Scene& sc, uint32_t* __restrict__ rgba, floa
             if (want == 0ull) break;
             if (q_head == q_count) {
                 if (next_samp >= n_samp) {           // this unit's camera rays are all traced: open the next unit
-                    if (u0.open && u0.left == 0u) { write_unit(L, u0, accum, lane, true, rgba, linear); u0.open = false; }
-                    if (u1.open && u1.left == 0u) { write_unit(L, u1, accum + 3u * P, lane, true, rgba, linear); u1.open = false; }
+                    if (u0.open && u0.left == 0u) { write_unit(L, u0, accum, lane, true, rgba, linear, fold); u0.open = false; }
+                    if (u1.open && u1.left == 0u) { write_unit(L, u1, accum + 3u * P, lane, true, rgba, linear, fold1); u1.open = false; }
                     if (drained || (cur ? u0.open : u1.open)) break;
                     uint32_t unit = 0u;
                     if (lane == 0u) unit = atomicAdd(work, 1u);
@@ -995,7 +1023,7 @@ RT_DEV void render_queue_body(const Scene& sc, uint32_t* __restrict__ rgba, floa
                 }
                 uint32_t completed = 0u;
                 primary_batch(sc, tile, geo0, cam, L, seed, T, cur ? u1 : u0, cur, next_samp, n_samp,
-                              accum + (cur ? 3u * P : 0u), q, cand, q_count, completed, nseg, st);
+                              accum, fold, q, cand, q_count, completed, nseg, st);
                 q_head = 0u;
                 next_samp = next_samp + 64u < n_samp ? next_samp + 64u : n_samp;
                 if (cur) u1.left -= completed; else u0.left -= completed;
@@ -1024,7 +1052,7 @@ RT_DEV void render_queue_body(const Scene& sc, uint32_t* __restrict__ rgba, floa
             nseg++;
             V3 color;
             if (shade_segment(sc, L, seed, b, pixel, s, band, p, color, st)) {
-                add_sample(accum, P, pixslot, color);
+                add_sample(accum, P, pixslot, s, L.samples_per_pixel, color, fold);
                 active = false;
                 need = true;
                 finished = true;
@@ -1059,11 +1087,12 @@ RT_DEV void render_queue_body(const Scene& sc, uint32_t* __restrict__ rgba, floa
 // the tile's geo0 copy) or one segment of its bounce rays (scan_tile), whichever keeps its lanes busy: camera
 // rays when a lane is out of work and the queue is empty, bounce rays otherwise.
 //   LDS: [geo S float4][geo0 S float4], S = RT_Q_STREAM_TILE, then per wavefront as in render_queue_body.
+template <bool FOLD>
 RT_DEV void render_queue_stream_body(const Scene& sc, uint32_t* __restrict__ rgba, float4* __restrict__ linear,
                                      unsigned long long* __restrict__ segments, uint32_t* __restrict__ work,
-                                     const RtCamera& cam, const RtLaunch& L) {
+                                     float4* __restrict__ fold_all, const RtCamera& cam, const RtLaunch& L) {
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform: kept in a scalar register
     const uint64_t seed = ((uint64_t)L.seed_hi << 32) | L.seed_lo;
     const uint32_t flags = L.flags;
     const uint32_t P = L.unit_w * L.unit_h;
@@ -1081,6 +1110,8 @@ RT_DEV void render_queue_stream_body(const Scene& sc, uint32_t* __restrict__ rgb
     unsigned long long* accum = reinterpret_cast<unsigned long long*>(mine + RT_Q_CAND_CAP * 128u);
     uint32_t* q = reinterpret_cast<uint32_t*>(mine + RT_Q_CAND_CAP * 128u + 48u * P);
     for (uint32_t k = lane; k < 6u * P; k += 64u) accum[k] = 0ull;
+    float4* fold = FOLD ? fold_all + (size_t)(blockIdx.x * (blockDim.x >> 6) + wave) * (2u * P * (size_t)L.samples_per_pixel) : nullptr;
+    const float4* fold1 = FOLD ? fold + (size_t)P * L.samples_per_pixel : nullptr;
     // camera-centre constants of geo0.w = t + m (operations of scan_tile)
     const V3 op0 = vsub(ld3(cam.center), T);
     const V3 w0 = v3(2.0f * op0.x, 2.0f * op0.y, 2.0f * op0.z);
@@ -1101,8 +1132,8 @@ RT_DEV void render_queue_stream_body(const Scene& sc, uint32_t* __restrict__ rgb
     float band = 0.0f;
 
     for (;;) {
-        if (u0.open && u0.left == 0u) { write_unit(L, u0, accum, lane, true, rgba, linear); u0.open = false; }
-        if (u1.open && u1.left == 0u) { write_unit(L, u1, accum + 3u * P, lane, true, rgba, linear); u1.open = false; }
+        if (u0.open && u0.left == 0u) { write_unit(L, u0, accum, lane, true, rgba, linear, fold); u0.open = false; }
+        if (u1.open && u1.left == 0u) { write_unit(L, u1, accum + 3u * P, lane, true, rgba, linear, fold1); u1.open = false; }
 
         // lanes without a path take queued rays
         unsigned long long want = __ballot(need);
@@ -1194,7 +1225,7 @@ RT_DEV void render_queue_stream_body(const Scene& sc, uint32_t* __restrict__ rgb
                 sphere = (uint32_t)b.idx;
                 V3 color;
                 if (shade_segment(sc, L, seed, b, bpixel, bs, bband, bp, color, st)) {
-                    add_sample(accum + (cur ? 3u * P : 0u), P, bpix, color);
+                    add_sample(accum, P, bpix + (cur ? 3u * P : 0u), bs, L.samples_per_pixel, color, fold);
                     bdone = true;
                 } else {
                     cont = true;
@@ -1209,7 +1240,7 @@ RT_DEV void render_queue_stream_body(const Scene& sc, uint32_t* __restrict__ rgb
             nseg++;
             V3 color;
             if (shade_segment(sc, L, seed, b, pixel, s, band, p, color, st)) {
-                add_sample(accum, P, pixslot, color);
+                add_sample(accum, P, pixslot, s, L.samples_per_pixel, color, fold);
                 active = false;
                 need = true;
                 finished = true;
@@ -1232,28 +1263,45 @@ RT_DEV void render_queue_stream_body(const Scene& sc, uint32_t* __restrict__ rgb
 
 extern "C" __global__ void __launch_bounds__(1024)
 rt_render(const float4* geom, const float4* exact, const float4* shade, const uint32_t* mat, uint32_t* rgba,
-          float4* linear, unsigned long long* segments, uint32_t* work, RtCamera cam, RtLaunch L) {
+          float4* linear, unsigned long long* segments, uint32_t* work, float4* fold, RtCamera cam, RtLaunch L) {
     Scene sc = {geom, exact, shade, mat};
     render_body<false>(sc, rgba, linear, segments, work, cam, L);
 }
 
 extern "C" __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(5)))
 rt_render_queue(const float4* geom, const float4* exact, const float4* shade, const uint32_t* mat, uint32_t* rgba,
-                float4* linear, unsigned long long* segments, uint32_t* work, RtCamera cam, RtLaunch L) {
+                float4* linear, unsigned long long* segments, uint32_t* work, float4* fold, RtCamera cam, RtLaunch L) {
     Scene sc = {geom, exact, shade, mat};
-    render_queue_body(sc, rgba, linear, segments, work, cam, L);
+    render_queue_body<false>(sc, rgba, linear, segments, work, fold, cam, L);
 }
 
 extern "C" __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(5)))
 rt_render_queue_stream(const float4* geom, const float4* exact, const float4* shade, const uint32_t* mat, uint32_t* rgba,
-                       float4* linear, unsigned long long* segments, uint32_t* work, RtCamera cam, RtLaunch L) {
+                       float4* linear, unsigned long long* segments, uint32_t* work, float4* fold, RtCamera cam, RtLaunch L) {
     Scene sc = {geom, exact, shade, mat};
-    render_queue_stream_body(sc, rgba, linear, segments, work, cam, L);
+    render_queue_stream_body<false>(sc, rgba, linear, segments, work, fold, cam, L);
+}
+
+// The same two kernels in fold-order mode (RtParams.sample_chunk = 0): finished samples are parked in the
+// wavefront's workspace and added in sample order in fp32 when their unit is complete -- the reference's
+// summation order (ray.cu:123-129, lib.rs:228-231) at the speed of the exact-accumulation kernels.
+extern "C" __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(5)))
+rt_render_queue_fold(const float4* geom, const float4* exact, const float4* shade, const uint32_t* mat, uint32_t* rgba,
+                     float4* linear, unsigned long long* segments, uint32_t* work, float4* fold, RtCamera cam, RtLaunch L) {
+    Scene sc = {geom, exact, shade, mat};
+    render_queue_body<true>(sc, rgba, linear, segments, work, fold, cam, L);
+}
+
+extern "C" __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(5)))
+rt_render_queue_stream_fold(const float4* geom, const float4* exact, const float4* shade, const uint32_t* mat, uint32_t* rgba,
+                            float4* linear, unsigned long long* segments, uint32_t* work, float4* fold, RtCamera cam, RtLaunch L) {
+    Scene sc = {geom, exact, shade, mat};
+    render_queue_stream_body<true>(sc, rgba, linear, segments, work, fold, cam, L);
 }
 
 extern "C" __global__ void __launch_bounds__(1024)
 rt_render_stream(const float4* geom, const float4* exact, const float4* shade, const uint32_t* mat, uint32_t* rgba,
-                 float4* linear, unsigned long long* segments, uint32_t* work, RtCamera cam, RtLaunch L) {
+                 float4* linear, unsigned long long* segments, uint32_t* work, float4* fold, RtCamera cam, RtLaunch L) {
     Scene sc = {geom, exact, shade, mat};
     render_body<true>(sc, rgba, linear, segments, work, cam, L);
 }

@@ -103,6 +103,8 @@ def lib():
                                        C.c_uint32, C.c_uint32, vp]
         L.or64_unit_vector.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, vp]
         L.or32_unit_vector.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, vp]
+        L.or64_render_sig.argtypes = L.or64_render.argtypes + [vp]
+        L.or32_render_sig.argtypes = L.or32_render.argtypes + [vp]
         L.or32_show_random.argtypes = [C.c_uint32, C.c_uint32, C.c_uint64, C.c_int, vp]
         _lib = L
     return _lib
@@ -167,8 +169,8 @@ def primary_hits(cam, spheres, t_min=0.001, t_max=float("inf"), flags=0, row0=0,
     return (idx, t, point, normal) if details else idx
 
 
-def render(cam, spheres, params, row0=0, rows=None, threads=None):
-    """Full render; returns (rgba u8 [rows,W,4], linear [rows,W,4], segments)."""
+def render(cam, spheres, params, row0=0, rows=None, threads=None, signatures=False):
+    """Full render; returns (rgba u8 [rows,W,4], linear [rows,W,4], segments[, path signatures u64 [rows,W]])."""
     f64 = isinstance(cam, OrCameraD)
     W, H = cam.image_width, cam.image_height
     rows = H - row0 if rows is None else rows
@@ -176,6 +178,12 @@ def render(cam, spheres, params, row0=0, rows=None, threads=None):
     rgba = np.empty((rows, W, 4), np.uint8)
     lin = np.empty((rows, W, 4), np.float64 if f64 else np.float32)
     seg = C.c_uint64(0)
+    if signatures:
+        sig = np.empty((rows, W), np.uint64)
+        fn = lib().or64_render_sig if f64 else lib().or32_render_sig
+        fn(C.byref(cam), _ptr(sp), len(sp), C.addressof(params), row0, rows, threads or default_threads(),
+           _ptr(rgba), _ptr(lin), C.byref(seg), _ptr(sig))
+        return rgba, lin, seg.value, sig
     fn = lib().or64_render if f64 else lib().or32_render
     fn(C.byref(cam), _ptr(sp), len(sp), C.addressof(params), row0, rows, threads or default_threads(),
        _ptr(rgba), _ptr(lin), C.byref(seg))
