@@ -144,7 +144,7 @@ def main():
     my_tiles = len(tiles.tiles_of_rank(H, rank, world))
     d_rgba = tiles.local_buffer(H, W, world, dev)          # compact per-rank buffer
     # rank 0: every rank's buffer back to back (the gather's destination) and the frame in image order
-    gathered = torch.empty((world,) + tuple(d_rgba.shape), dtype=torch.uint8, device=dev) if (world > 1 and rank == 0) else None
+    gathered = tiles.gathered_buffer(d_rgba, world) if (world > 1 and rank == 0) else None
     d_frame = torch.empty((H, W, 4), dtype=torch.uint8, device=dev) if (world > 1 and rank == 0) else None
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
     torch.cuda.synchronize()                               # buffers zero-filled before the library's stream writes them
@@ -157,7 +157,7 @@ def main():
         # RCCL gather over xGMI (<= 4.2 MB per peer at 4K) into the contiguous buffer, then the library's copy
         # kernel puts the tiles in image order.  The gather's time on rank 0 includes waiting for the slowest rank.
         ev[0].record()
-        dist.gather(d_rgba, [gathered[r] for r in range(world)] if rank == 0 else None, dst=0)
+        tiles.gather_contiguous(d_rgba, gathered, rank, world)
         ev[1].record()
         ev[1].synchronize()                                # d_rgba is rewritten by the next render on another stream
         gather_ms = ev[0].elapsed_time(ev[1])

@@ -41,6 +41,22 @@ def assemble(gathered, height, tile_rows=TILE_ROWS):
     return g.permute(1, 0, 2, 3, 4).reshape(k * world * tile_rows, W, C)[:height]
 
 
+def gathered_buffer(local, world):
+    """Rank 0's destination of the gather: every rank's compact buffer back to back, [world, rows, W, C] --
+    the layout rt_assemble_tiles (the library's copy kernel) reads."""
+    return torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
+
+
+def gather_contiguous(local, gathered, rank, world):
+    """One gather of every rank's compact buffer into rank 0's contiguous `gathered` (from gathered_buffer;
+    None on the other ranks).  The collective's receive list is the buffer's own slices, so no copy follows."""
+    if world == 1:
+        if gathered is not None:
+            gathered[0].copy_(local)
+        return
+    dist.gather(local, [gathered[r] for r in range(world)] if rank == 0 else None, dst=0)
+
+
 def gather_frame(local, height, rank, world, scratch=None, tile_rows=TILE_ROWS):
     """Gathers every rank's compact buffer to rank 0 and returns the assembled frame there (None elsewhere).
     `scratch` may hold a reusable list of `world` receive buffers on rank 0."""

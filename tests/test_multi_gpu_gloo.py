@@ -34,6 +34,13 @@ WORKER = textwrap.dedent("""
         local[k * tiles.TILE_ROWS:k * tiles.TILE_ROWS + rows] = torch.from_numpy(rgba)
         rays += seg
     frame = tiles.gather_frame(local, H, rank, world)
+    # the form bench.py uses: one gather into a contiguous [world, rows, W, 4] buffer (what the library's copy
+    # kernel rt_assemble_tiles reads on the GPU); here the same permutation is done on the host
+    gathered = tiles.gathered_buffer(local, world) if rank == 0 else None
+    tiles.gather_contiguous(local, gathered, rank, world)
+    if rank == 0:
+        assert gathered.is_contiguous()
+        assert torch.equal(tiles.assemble([gathered[r] for r in range(world)], H), frame)
     total = torch.tensor([rays], dtype=torch.int64)
     dist.all_reduce(total)
     if rank == 0:
