@@ -164,15 +164,13 @@ RT_DEV void drain(const Tile& tile, int base, Cand& c, V3 o, V3 d, float a, floa
 #ifdef RT_EXP_DRAIN2
     for (int twice = 0; twice < 2; twice++)   // cost experiment: a second pass changes nothing (the bound is strict)
 #endif
-    for (uint32_t k = 0; __ballot(k < c.n) != 0ull; k++) {
+    for (uint32_t k = 0; k < c.n; k++) {                        // a lane leaves when its list is done
         st.wave(3);
-        if (k < c.n) {
-            uint32_t i = c.col[k * 64u];
-            float4 g = tile.exa[i];
-            float h, ncc, disc;
-            sphere_terms(g.x, g.y, g.z, g.w, o, d, a, h, ncc, disc);
-            accept_exact(h, ncc, disc, a, t_min, base + (int)i, b);
-        }
+        uint32_t i = c.col[k * 64u];
+        float4 g = tile.exa[i];
+        float h, ncc, disc;
+        sphere_terms(g.x, g.y, g.z, g.w, o, d, a, h, ncc, disc);
+        accept_exact(h, ncc, disc, a, t_min, base + (int)i, b);
     }
     c.n = 0u;
 }
@@ -197,14 +195,13 @@ RT_DEV void decode_block(const Tile& tile, int base, uint32_t blk, uint32_t k, u
         c.n = n0;
     }
 #endif
-    while (__ballot(bits != 0u) != 0ull) {
+    while (bits != 0u) {                                            // a lane leaves when its bits are used up
         st.wave(4);
-        if (bits != 0u) {
-            st.add(2, 1u);
-            uint32_t pos = 31u - (uint32_t)__clz((int)bits);        // highest bit = lowest sphere index first
-            push(c, blk + (k - 1u - pos));
-            bits &= ~(1u << pos);
-        }
+        st.add(2, 1u);
+        uint32_t pos = 31u - (uint32_t)__clz((int)bits);            // highest bit = lowest sphere index first
+        push(c, blk + (k - 1u - pos));
+        bits &= ~(1u << pos);
+        // a full list: the lanes still decoding drain theirs together (the others' lists have room left)
         if (__ballot(c.n >= c.cap) != 0ull) { st.lap(10); drain(tile, base, c, o, d, a, t_min, b, st); st.lap(11); }
     }
     st.lap(10);
@@ -1003,32 +1000,9 @@ RT_DEV void render_queue_body(const Scene& sc, uint32_t* __restrict__ rgba, floa
         if (u0.open && u0.left == 0u) { write_unit(L, u0, accum, lane, true, rgba, linear, fold); u0.open = false; }
         if (u1.open && u1.left == 0u) { write_unit(L, u1, accum + 3u * P, lane, true, rgba, linear, fold1); u1.open = false; }
 
-        // lanes without a path take queued rays; an empty queue is refilled from the next camera rays
-        for (;;) {
-            const unsigned long long want = __ballot(need);
-            if (want == 0ull) break;
-            if (q_head == q_count) {
-                if (next_samp >= n_samp) {           // this unit's camera rays are all traced: open the next unit
-                    if (u0.open && u0.left == 0u) { write_unit(L, u0, accum, lane, true, rgba, linear, fold); u0.open = false; }
-                    if (u1.open && u1.left == 0u) { write_unit(L, u1, accum + 3u * P, lane, true, rgba, linear, fold1); u1.open = false; }
-                    if (drained || (cur ? u0.open : u1.open)) break;
-                    uint32_t unit = 0u;
-                    if (lane == 0u) unit = atomicAdd(work, 1u);
-                    unit = (uint32_t)__builtin_amdgcn_readfirstlane((int)unit);
-                    if (unit >= L.n_units) { drained = true; break; }
-                    cur ^= 1u;
-                    next_samp = 0u;
-                    if (cur) u1 = open_unit(L, unit, n_samp); else u0 = open_unit(L, unit, n_samp);
-                    if (n_samp == 0u) continue;
-                }
-                uint32_t completed = 0u;
-                primary_batch(sc, tile, geo0, cam, L, seed, T, cur ? u1 : u0, cur, next_samp, n_samp,
-                              accum, fold, q, cand, q_count, completed, nseg, st);
-                q_head = 0u;
-                next_samp = next_samp + 64u < n_samp ? next_samp + 64u : n_samp;
-                if (cur) u1.left -= completed; else u0.left -= completed;
-                continue;
-            }
+        // lanes without a path take queued rays
+        unsigned long long want = __ballot(need);
+        if (want != 0ull && q_head < q_count) {
             const uint32_t j = q_head + __builtin_amdgcn_mbcnt_hi((uint32_t)(want >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)want, 0u));
             if (need && j < q_count) {
                 take_queued(sc, L, q, j, u0, u1, p, s, pixel, pixslot, band);
@@ -1037,6 +1011,38 @@ RT_DEV void render_queue_body(const Scene& sc, uint32_t* __restrict__ rgba, floa
             }
             const uint32_t asked = (uint32_t)__popcll(want);
             q_head += asked < q_count - q_head ? asked : q_count - q_head;
+            want = __ballot(need);
+        }
+        // lanes still without one (the queue is empty now): trace the next camera rays, then come round again
+        if (want != 0ull) {
+            bool can = true;
+            if (next_samp >= n_samp) {               // this unit's camera rays are all traced: open the next unit
+                if (drained || (cur ? u0.open : u1.open)) {
+                    can = false;
+                } else {
+                    uint32_t unit = 0u;
+                    if (lane == 0u) unit = atomicAdd(work, 1u);
+                    unit = (uint32_t)__builtin_amdgcn_readfirstlane((int)unit);
+                    if (unit >= L.n_units) {
+                        drained = true;
+                        can = false;
+                    } else {
+                        cur ^= 1u;
+                        next_samp = 0u;
+                        if (cur) u1 = open_unit(L, unit, n_samp); else u0 = open_unit(L, unit, n_samp);
+                        if (n_samp == 0u) continue;
+                    }
+                }
+            }
+            if (can) {
+                uint32_t completed = 0u;
+                primary_batch(sc, tile, geo0, cam, L, seed, T, cur ? u1 : u0, cur, next_samp, n_samp,
+                              accum, fold, q, cand, q_count, completed, nseg, st);
+                q_head = 0u;
+                next_samp = next_samp + 64u < n_samp ? next_samp + 64u : n_samp;
+                if (cur) u1.left -= completed; else u0.left -= completed;
+                continue;
+            }
         }
 
         const bool more = active || q_head < q_count || !drained || next_samp < n_samp || u0.open || u1.open;
