@@ -485,7 +485,8 @@ int rt_upload_scene(rt_ctx* c, const RtSphere* spheres, uint32_t n) {
     // geom:  scan-filter data {c - T, m} per sphere: T = component-wise median of the centres,
     //        m = r*r(1+2^-17) - |c-T|^2 (1-2^-18), rounded up (see scan_tile in rt_kernels.hip)
     // exact: {c, r*r} per sphere for the exact test
-    // shade: {cx,cy,cz,radius} {albedo rgb, fuzz|ior} per sphere;  mat: material tag per sphere
+    // shade: {cx,cy,cz,radius} {albedo rgb, fuzz|ior} per sphere, then {1/ior, r0 in, r0 out, 0} per sphere (glass only);
+    //        mat: material tag per sphere
     float T[3] = {0.0f, 0.0f, 0.0f};
     if (n) {
         std::vector<float> v(n);
@@ -495,7 +496,7 @@ int rt_upload_scene(rt_ctx* c, const RtSphere* spheres, uint32_t n) {
             T[k] = std::isfinite(v[n / 2]) ? v[n / 2] : 0.0f;
         }
     }
-    std::vector<float> geom((size_t)n_padded * 4), exact((size_t)n_padded * 4), shade((size_t)n_padded * 8);
+    std::vector<float> geom((size_t)n_padded * 4), exact((size_t)n_padded * 4), shade((size_t)n_padded * 12, 0.0f);
     std::vector<uint32_t> mat(n_padded);
     for (uint32_t i = 0; i < n_padded; i++) {
         float* g = &geom[4 * (size_t)i];
@@ -520,6 +521,17 @@ int rt_upload_scene(rt_ctx* c, const RtSphere* spheres, uint32_t n) {
             s[0] = sp.center[0]; s[1] = sp.center[1]; s[2] = sp.center[2]; s[3] = sp.radius;
             s[4] = sp.albedo[0]; s[5] = sp.albedo[1]; s[6] = sp.albedo[2]; s[7] = param;
             mat[i] = sp.material;
+            if (sp.material == RT_MAT_DIELECTRIC) {
+                // constants of the book's dielectric, in the single-precision operations of the kernel's former
+                // inline code (and of the checker): 1/ior, and Schlick's r0 for a ray entering (ri = 1/ior) and leaving (ri = ior)
+                float* gt = &shade[8 * (size_t)n_padded + 4 * (size_t)i];
+                const float inv = 1.0f / param;
+                float r0 = (1.0f - inv) / (1.0f + inv);
+                gt[0] = inv;
+                gt[1] = r0 * r0;
+                r0 = (1.0f - param) / (1.0f + param);
+                gt[2] = r0 * r0;
+            }
         } else {
             // padding up to the scan's unroll factor: m = -inf makes the filter value -inf, never a candidate
             g[0] = g[1] = g[2] = 0.0f; g[3] = -INFINITY;
@@ -535,11 +547,11 @@ int rt_upload_scene(rt_ctx* c, const RtSphere* spheres, uint32_t n) {
     c->have_scene = false;
     RT_HIP(c, hipMalloc(&c->d_geom, bytes));
     RT_HIP(c, hipMalloc(&c->d_exact, bytes));
-    RT_HIP(c, hipMalloc(&c->d_shade, 2 * bytes));
+    RT_HIP(c, hipMalloc(&c->d_shade, 3 * bytes));
     RT_HIP(c, hipMalloc(&c->d_mat, (size_t)n_padded * 4u));
     RT_HIP(c, hipMemcpy(c->d_geom, geom.data(), bytes, hipMemcpyHostToDevice));
     RT_HIP(c, hipMemcpy(c->d_exact, exact.data(), bytes, hipMemcpyHostToDevice));
-    RT_HIP(c, hipMemcpy(c->d_shade, shade.data(), 2 * bytes, hipMemcpyHostToDevice));
+    RT_HIP(c, hipMemcpy(c->d_shade, shade.data(), 3 * bytes, hipMemcpyHostToDevice));
     RT_HIP(c, hipMemcpy(c->d_mat, mat.data(), (size_t)n_padded * 4u, hipMemcpyHostToDevice));
     for (int k = 0; k < 3; k++) c->translate[k] = T[k];
     c->n_spheres = n;

@@ -207,6 +207,13 @@ RT_DEV void decode_block(const Tile& tile, int base, uint32_t blk, uint32_t k, u
     st.lap(10);
 }
 
+// 1/|d| for the scan filter, times 1 + 2^-19.  v_rsq_f32 is accurate to 1 ulp, which is also what a correctly
+// rounded square root followed by a correctly rounded divide guarantee, so the derivation below holds as it
+// stands; the filter is not part of the arithmetic contract (only the exact test decides), and the hardware
+// instruction replaces some 25 operations per scan.  d.d = 0 or denormal gives +inf: every key is then +inf or a
+// (positive) NaN, i.e. a candidate, and the exact test rejects.
+RT_DEV float filter_inv_len(float a) { return __builtin_amdgcn_rsqf(a) * (1.0f + 0x1p-19f); }
+
 // Scan `count` (a multiple of RT_SCAN_UNROLL) spheres staged in LDS; every lane of the wavefront reads
 // the same float4 per sphere.  The scan only has to list, per lane, a SUPERSET of the spheres the exact
 // test can accept; the exact test (sqrt, two divides, ~70 operations) then runs once per listed sphere
@@ -241,26 +248,36 @@ RT_DEV void scan_tile(const Tile& tile, uint32_t count, int base, V3 T,
                       V3 o, V3 d, float a, float t_min, Best& b, Cand& c, Stats& st) {
     st.wave(1);
     const V3 op = vsub(o, T);
-    const float inv_len = (1.0f / sqrtf(a)) * (1.0f + 0x1p-19f);
+    const float inv_len = filter_inv_len(a);
     const V3 uf = v3(d.x * inv_len, d.y * inv_len, d.z * inv_len);
     const float e = -vdot(uf, op);
     const V3 w = v3(2.0f * op.x, 2.0f * op.y, 2.0f * op.z);
     const float k0 = -(vdot(op, op) * (1.0f - 0x1p-18f));
-    for (uint32_t blk = 0; blk < count; blk += 32u) {
-        const uint32_t k = (count - blk) < 32u ? (count - blk) : 32u;   // spheres in this block, multiple of 8
-        uint32_t miss = 0u;                                            // bit j set: sphere blk + (k-1-j) cannot be hit
-        for (uint32_t i = 0; i < k; i += RT_SCAN_UNROLL) {
-            float4 s[RT_SCAN_UNROLL];
+    // 8 spheres: eight 16-byte LDS reads, then 72 operations; the sign bits are shifted into `miss`
+    auto step8 = [&](const float4* p8, uint32_t& miss) {
+        float4 s[RT_SCAN_UNROLL];
 #pragma unroll
-            for (uint32_t u = 0; u < RT_SCAN_UNROLL; u++) s[u] = tile.geo[blk + i + u];
+        for (uint32_t u = 0; u < RT_SCAN_UNROLL; u++) s[u] = p8[u];
 #pragma unroll
-            for (uint32_t u = 0; u < RT_SCAN_UNROLL; u++) {
-                const float t = fmaf(w.z, s[u].z, fmaf(w.y, s[u].y, fmaf(w.x, s[u].x, k0)));
-                const float g = fmaf(uf.z, s[u].z, fmaf(uf.y, s[u].y, fmaf(uf.x, s[u].x, e)));
-                const float key = fmaf(g, g, t) + s[u].w;
-                miss = __builtin_amdgcn_alignbit(miss, __float_as_uint(key), 31u);
-            }
+        for (uint32_t u = 0; u < RT_SCAN_UNROLL; u++) {
+            const float t = fmaf(w.z, s[u].z, fmaf(w.y, s[u].y, fmaf(w.x, s[u].x, k0)));
+            const float g = fmaf(uf.z, s[u].z, fmaf(uf.y, s[u].y, fmaf(uf.x, s[u].x, e)));
+            const float key = fmaf(g, g, t) + s[u].w;
+            miss = __builtin_amdgcn_alignbit(miss, __float_as_uint(key), 31u);
         }
+    };
+    uint32_t blk = 0u;
+    for (; blk + 32u <= count; blk += 32u) {                           // full blocks: one address, constant offsets
+        uint32_t miss = 0u;                                            // bit j set: sphere blk + (31-j) cannot be hit
+#pragma unroll
+        for (uint32_t i = 0; i < 32u; i += RT_SCAN_UNROLL) step8(tile.geo + blk + i, miss);
+        st.lap(9);
+        decode_block(tile, base, blk, 32u, miss, o, d, a, t_min, b, c, st);
+    }
+    if (blk < count) {                                                 // the last 8, 16 or 24 spheres
+        const uint32_t k = count - blk;
+        uint32_t miss = 0u;
+        for (uint32_t i = 0; i < k; i += RT_SCAN_UNROLL) step8(tile.geo + blk + i, miss);
         st.lap(9);
         decode_block(tile, base, blk, k, miss, o, d, a, t_min, b, c, st);
     }
@@ -278,23 +295,32 @@ RT_DEV void scan_primary(const float4* __restrict__ geo0, const Tile& tile, uint
                          V3 o, V3 d, float a, float t_min, Best& b, Cand& c, Stats& st) {
     st.wave(0);
     const V3 op = vsub(o, T);
-    const float inv_len = (1.0f / sqrtf(a)) * (1.0f + 0x1p-19f);
+    const float inv_len = filter_inv_len(a);
     const V3 uf = v3(d.x * inv_len, d.y * inv_len, d.z * inv_len);
     const float e = -vdot(uf, op);
-    for (uint32_t blk = 0; blk < count; blk += 32u) {
-        const uint32_t k = (count - blk) < 32u ? (count - blk) : 32u;
-        uint32_t miss = 0u;
-        for (uint32_t i = 0; i < k; i += RT_SCAN_UNROLL) {
-            float4 s[RT_SCAN_UNROLL];
+    auto step8 = [&](const float4* p8, uint32_t& miss) {
+        float4 s[RT_SCAN_UNROLL];
 #pragma unroll
-            for (uint32_t u = 0; u < RT_SCAN_UNROLL; u++) s[u] = geo0[blk + i + u];
+        for (uint32_t u = 0; u < RT_SCAN_UNROLL; u++) s[u] = p8[u];
 #pragma unroll
-            for (uint32_t u = 0; u < RT_SCAN_UNROLL; u++) {
-                const float g = fmaf(uf.z, s[u].z, fmaf(uf.y, s[u].y, fmaf(uf.x, s[u].x, e)));
-                const float key = fmaf(g, g, s[u].w);
-                miss = __builtin_amdgcn_alignbit(miss, __float_as_uint(key), 31u);
-            }
+        for (uint32_t u = 0; u < RT_SCAN_UNROLL; u++) {
+            const float g = fmaf(uf.z, s[u].z, fmaf(uf.y, s[u].y, fmaf(uf.x, s[u].x, e)));
+            const float key = fmaf(g, g, s[u].w);
+            miss = __builtin_amdgcn_alignbit(miss, __float_as_uint(key), 31u);
         }
+    };
+    uint32_t blk = 0u;
+    for (; blk + 32u <= count; blk += 32u) {
+        uint32_t miss = 0u;
+#pragma unroll
+        for (uint32_t i = 0; i < 32u; i += RT_SCAN_UNROLL) step8(geo0 + blk + i, miss);
+        st.lap(15);
+        decode_block(tile, base, blk, 32u, miss, o, d, a, t_min, b, c, st);
+    }
+    if (blk < count) {
+        const uint32_t k = count - blk;
+        uint32_t miss = 0u;
+        for (uint32_t i = 0; i < k; i += RT_SCAN_UNROLL) step8(geo0 + blk + i, miss);
         st.lap(15);
         decode_block(tile, base, blk, k, miss, o, d, a, t_min, b, c, st);
     }
@@ -306,7 +332,8 @@ RT_DEV void scan_primary(const float4* __restrict__ geo0, const Tile& tile, uint
 struct Scene {
     const float4* __restrict__ geom;    // filter data {c - T, m} per sphere, n_padded entries
     const float4* __restrict__ exact;   // {c, r*r} per sphere, n_padded entries
-    const float4* __restrict__ shade;   // per sphere two float4: {cx, cy, cz, radius}, {albedo r, g, b, fuzz | ior}
+    const float4* __restrict__ shade;   // per sphere two float4: {cx, cy, cz, radius}, {albedo r, g, b, fuzz | ior}; after the
+                                        // 2 * n_padded of those, one float4 per sphere with the glass constants (see scatter)
     const uint32_t* __restrict__ mat;   // material tag per sphere
 };
 
@@ -341,8 +368,8 @@ RT_DEV V3 sky(V3 d, float blend) {
 // (seed, pixel, sample, k) is started only by a material that draws from it: Lambertian and metal with
 // fuzz > 0 draw the unit-vector tries, glass draws one uniform (reflect or refract), a mirror (fuzz 0) draws
 // nothing -- a wavefront whose lanes all hit mirrors does no integer work here at all.
-RT_DEV V3 scatter(uint32_t mat, float param, V3 d, const HitInfo& h, uint64_t seed, uint32_t pixel, uint32_t s,
-                  uint32_t k, uint32_t flags, Stats& st) {
+RT_DEV V3 scatter(uint32_t mat, float param, const float4* __restrict__ glass_terms, V3 d, const HitInfo& h, uint64_t seed,
+                  uint32_t pixel, uint32_t s, uint32_t k, uint32_t flags, Stats& st) {
     const bool band = (flags & RT_FLAG_BAND_ALBEDO) != 0u;
     const bool glass = !band && mat == RT_MAT_DIELECTRIC;
     const bool wants_unit = band || mat == RT_MAT_DIFFUSE || (mat == RT_MAT_REFLECT && param != 0.0f);
@@ -377,14 +404,16 @@ RT_DEV V3 scatter(uint32_t mat, float param, V3 d, const HitInfo& h, uint64_t se
         if (wants_unit) out = v3(fmaf(ru.x, param, ur.x), fmaf(ru.y, param, ur.y), fmaf(ru.z, param, ur.z));
     } else {
         // Dielectric ("Ray Tracing in One Weekend" section 11): Snell refraction, Schlick reflectance.
-        float ri = h.front ? 1.0f / param : param;
+        // the sphere's constants, computed once at upload with the same single-precision operations:
+        // {1/ior, r0 entering, r0 leaving, -}, r0 = ((1 - ri) / (1 + ri))^2 for ri = 1/ior and ri = ior
+        const float4 gt = *glass_terms;
+        float ri = h.front ? gt.x : param;
         V3 ud = vunit(d);
         float udn = vdot(ud, n);
         float cos_t = fminf(-udn, 1.0f);
         float sin_t = sqrtf(fmaf(-cos_t, cos_t, 1.0f));
         bool cannot = ri * sin_t > 1.0f;
-        float r0 = (1.0f - ri) / (1.0f + ri);
-        r0 = r0 * r0;
+        float r0 = h.front ? gt.y : gt.z;
         float x = 1.0f - cos_t;
         float x2 = x * x;
         float x5 = x2 * x2 * x;
@@ -454,7 +483,7 @@ RT_DEV bool map_pixel(const RtLaunch& L, uint32_t wave_tile, uint32_t lane, uint
 }
 
 // Dynamic LDS: [geo: S float4][exa: S float4][candidate lists: waves x RT_CAND_CAP x 64 u16]
-// [accumulators: waves x 2 slots x 3 x P u64, P = pixels per unit], S = min(n_padded, RT_TILE_SPHERES)
+// [accumulators: waves x 2 slots x P x 3 u64 (r, g, b of a pixel side by side), P = pixels per unit], S = min(n_padded, RT_TILE_SPHERES)
 extern __shared__ float4 rt_lds[];
 
 RT_DEV uint32_t tile_capacity(const RtLaunch& L) { return L.n_padded < RT_TILE_SPHERES ? L.n_padded : RT_TILE_SPHERES; }
@@ -515,7 +544,7 @@ RT_DEV float fixed_mean(long long sum, uint32_t spp) { return (float)((double)su
 //                segment per outer iteration.
 struct Item {
     uint32_t x, y, pixel;       // image coordinates, global pixel index (RNG key)
-    uint32_t pix;               // index in the unit's accumulators, + 3*P if the item belongs to slot 1
+    uint32_t pix;               // first of the pixel's three accumulators: 3 * (pixel of the unit), + 3*P if the item belongs to slot 1
     uint32_t s, s_end;          // current sample and end of the run
     float band;                 // lib.rs:225-226 reflectance of the column
 };
@@ -563,15 +592,15 @@ RT_DEV void write_unit(const RtLaunch& L, const Slot& u, unsigned long long* acc
             const float fs = (float)L.samples_per_pixel;         // ray.cu:129, lib.rs:231
             mean = v3(total.x / fs, total.y / fs, total.z / fs);
         } else if (exact_sum) {
-            mean = v3(fixed_mean((long long)acc[lane], L.samples_per_pixel),
-                      fixed_mean((long long)acc[P + lane], L.samples_per_pixel),
-                      fixed_mean((long long)acc[2u * P + lane], L.samples_per_pixel));
+            mean = v3(fixed_mean((long long)acc[3u * lane], L.samples_per_pixel),
+                      fixed_mean((long long)acc[3u * lane + 1u], L.samples_per_pixel),
+                      fixed_mean((long long)acc[3u * lane + 2u], L.samples_per_pixel));
         } else {
             const float fs = (float)L.samples_per_pixel;         // ray.cu:129, lib.rs:231
-            mean = v3(__uint_as_float((uint32_t)acc[lane]) / fs, __uint_as_float((uint32_t)acc[P + lane]) / fs,
-                      __uint_as_float((uint32_t)acc[2u * P + lane]) / fs);
+            mean = v3(__uint_as_float((uint32_t)acc[3u * lane]) / fs, __uint_as_float((uint32_t)acc[3u * lane + 1u]) / fs,
+                      __uint_as_float((uint32_t)acc[3u * lane + 2u]) / fs);
         }
-        acc[lane] = 0ull; acc[P + lane] = 0ull; acc[2u * P + lane] = 0ull;
+        acc[3u * lane] = 0ull; acc[3u * lane + 1u] = 0ull; acc[3u * lane + 2u] = 0ull;
         if (x < L.width && ly < L.rows_local && y < L.height) {
             const size_t k = (size_t)ly * L.width + x;
             rgba[k] = quant(mean.x, L.flags) | (quant(mean.y, L.flags) << 8) | (quant(mean.z, L.flags) << 16) | (255u << 24);
@@ -594,7 +623,7 @@ RT_DEV void render_body(const Scene& sc, uint32_t* __restrict__ rgba, float4* __
 
     Tile tile = {rt_lds, rt_lds + tile_capacity(L)};
     const V3 T = ld3(L.translate);
-    // per wavefront and slot: [3][P] 64-bit words, fixed-point sums (exact_sum) or the fp32 run sum bits
+    // per wavefront and slot: [P][3] 64-bit words, fixed-point sums (exact_sum) or the fp32 run sum bits
     unsigned long long* accum = accum_base(L) + wave * (6u * P);
     for (uint32_t k = lane; k < 6u * P; k += 64u) accum[k] = 0ull;
     if (!MULTI) {
@@ -651,7 +680,7 @@ RT_DEV void render_body(const Scene& sc, uint32_t* __restrict__ rgba, float4* __
                         const uint32_t ly = (cur ? u1.ly0 : u0.ly0) + dy;
                         it.x = (cur ? u1.x0 : u0.x0) + dx;
                         it.y = (cur ? u1.y0 : u0.y0) + dy;
-                        it.pix = pix + (cur ? 3u * P : 0u);
+                        it.pix = 3u * pix + (cur ? 3u * P : 0u);
                         it.pixel = it.y * L.width + it.x;
                         it.s = run_idx * L.chunk;
                         it.s_end = it.s + L.chunk < L.samples_per_pixel ? it.s + L.chunk : L.samples_per_pixel;
@@ -714,7 +743,7 @@ RT_DEV void render_body(const Scene& sc, uint32_t* __restrict__ rgba, float4* __
                 const float4 al = sc.shade[2 * b.idx + 1];
                 const uint32_t mat = sc.mat[b.idx];
                 HitInfo h = finish_hit(cr, b.t, o, d, flags);
-                V3 nd = scatter(mat, al.w, d, h, seed, it.pixel, it.s, seg + 1u, flags, st);
+                V3 nd = scatter(mat, al.w, sc.shade + 2u * L.n_padded + (uint32_t)b.idx, d, h, seed, it.pixel, it.s, seg + 1u, flags, st);
                 o = h.p;
                 d = nd;
                 if (flags & RT_FLAG_BAND_ALBEDO) {
@@ -747,12 +776,12 @@ RT_DEV void render_body(const Scene& sc, uint32_t* __restrict__ rgba, float4* __
                 } else {                                         // run complete: hand its sum to the pixel
                     if (exact_sum) {
                         atomicAdd(accum + it.pix, (unsigned long long)to_fixed(run.x));
-                        atomicAdd(accum + P + it.pix, (unsigned long long)to_fixed(run.y));
-                        atomicAdd(accum + 2u * P + it.pix, (unsigned long long)to_fixed(run.z));
+                        atomicAdd(accum + it.pix + 1u, (unsigned long long)to_fixed(run.y));
+                        atomicAdd(accum + it.pix + 2u, (unsigned long long)to_fixed(run.z));
                     } else {
                         accum[it.pix] = __float_as_uint(run.x);
-                        accum[P + it.pix] = __float_as_uint(run.y);
-                        accum[2u * P + it.pix] = __float_as_uint(run.z);
+                        accum[it.pix + 1u] = __float_as_uint(run.y);
+                        accum[it.pix + 2u] = __float_as_uint(run.z);
                     }
                     active = false;
                     need = true;
@@ -795,7 +824,7 @@ RT_DEV void render_body(const Scene& sc, uint32_t* __restrict__ rgba, float4* __
 // whose path has ended takes the next queued ray; when the queue is empty the next batch of camera rays
 // of the unit is traced.  Image and segment count are those of render_body with sample_chunk = 1, bit for bit.
 //   LDS: [geo S float4][geo0 S float4] then per wavefront
-//        [candidate lists RT_Q_CAND_CAP x 64 u16][accumulators 2 x 3 x P u64][queue RT_Q_WORDS x 64 u32]
+//        [candidate lists RT_Q_CAND_CAP x 64 u16][accumulators 2 x P x 3 u64][queue RT_Q_WORDS x 64 u32]
 // RT_Q_WORDS (rt_device.h) = 8 words per queued ray: origin xyz, direction xyz, sample,
 // (slot * 64 + pixel of unit) << 16 | sphere hit
 
@@ -811,7 +840,7 @@ RT_DEV bool shade_segment(const Scene& sc, const RtLaunch& L, uint64_t seed, con
         const float4 al = sc.shade[2 * b.idx + 1];
         const uint32_t mat = sc.mat[b.idx];
         HitInfo h = finish_hit(cr, b.t, p.o, p.d, flags);
-        V3 nd = scatter(mat, al.w, p.d, h, seed, pixel, s, p.seg + 1u, flags, st);
+        V3 nd = scatter(mat, al.w, sc.shade + 2u * L.n_padded + (uint32_t)b.idx, p.d, h, seed, pixel, s, p.seg + 1u, flags, st);
         p.o = h.p;
         p.d = nd;
         if (flags & RT_FLAG_BAND_ALBEDO) p.nb++;
@@ -837,19 +866,19 @@ RT_DEV float band_of(const RtLaunch& L, uint32_t x) {              // lib.rs:225
     return 0.1f + 0.2f * (float)(x / (gi ? gi : 1u));
 }
 
-// One finished sample.  acc = the wavefront's accumulators, pixslot = pixel of the unit (+ 3P for slot 1).
+// One finished sample.  acc = the wavefront's accumulators ([slot][pixel][r, g, b]), pixslot = 3 * pixel of the
+// unit (+ 3P for slot 1): the index of the pixel's first accumulator.
 // Exact mode: added to the pixel's fixed-point accumulators.  Fold-order mode (fold != NULL): stored at
 // [slot][pixel][sample] of the wavefront's workspace, to be added in sample order when the unit is complete.
 RT_DEV void add_sample(unsigned long long* acc, uint32_t P, uint32_t pixslot, uint32_t s, uint32_t spp, V3 color, float4* fold) {
     if (fold) {
-        const uint32_t slot = pixslot >= 3u * P ? 1u : 0u;
-        const uint32_t pix = pixslot - slot * 3u * P;
-        fold[((size_t)slot * P + pix) * spp + s] = make_float4(color.x, color.y, color.z, 0.0f);
+        const uint32_t sp = (pixslot * 43691u) >> 17;             // pixslot / 3 = slot * P + pixel (exact below 98,304)
+        fold[(size_t)sp * spp + s] = make_float4(color.x, color.y, color.z, 0.0f);
         return;
     }
     atomicAdd(acc + pixslot, (unsigned long long)to_fixed(color.x));
-    atomicAdd(acc + P + pixslot, (unsigned long long)to_fixed(color.y));
-    atomicAdd(acc + 2u * P + pixslot, (unsigned long long)to_fixed(color.z));
+    atomicAdd(acc + pixslot + 1u, (unsigned long long)to_fixed(color.y));
+    atomicAdd(acc + pixslot + 2u, (unsigned long long)to_fixed(color.z));
 }
 
 // Queue entry j becomes the lane's path: the ray that left the camera ray's hit, one segment done.
@@ -866,7 +895,7 @@ RT_DEV void take_queued(const Scene& sc, const RtLaunch& L, const uint32_t* q, u
     const uint32_t dx = pix & (L.unit_w - 1u), dy = pix >> L.unit_shift;
     const uint32_t x = (in1 ? u1.x0 : u0.x0) + dx, y = (in1 ? u1.y0 : u0.y0) + dy;
     pixel = y * L.width + x;
-    pixslot = pix + (in1 ? 3u * P : 0u);
+    pixslot = 3u * pix + (in1 ? 3u * P : 0u);
     p.seg = 1u;
     if (L.flags & RT_FLAG_BAND_ALBEDO) {
         band = band_of(L, x);
@@ -929,7 +958,7 @@ RT_DEV void primary_batch(const Scene& sc, const Tile& tile, const float4* __res
         sphere = (uint32_t)b.idx;
         V3 color;
         if (shade_segment(sc, L, seed, b, pixel, s, band, p, color, st)) {
-            add_sample(acc, P, pix + (slot ? 3u * P : 0u), s, L.samples_per_pixel, color, fold);
+            add_sample(acc, P, 3u * pix + (slot ? 3u * P : 0u), s, L.samples_per_pixel, color, fold);
             done = true;
         } else {
             cont = true;
@@ -1231,7 +1260,7 @@ RT_DEV void render_queue_stream_body(const Scene& sc, uint32_t* __restrict__ rgb
                 sphere = (uint32_t)b.idx;
                 V3 color;
                 if (shade_segment(sc, L, seed, b, bpixel, bs, bband, bp, color, st)) {
-                    add_sample(accum, P, bpix + (cur ? 3u * P : 0u), bs, L.samples_per_pixel, color, fold);
+                    add_sample(accum, P, 3u * bpix + (cur ? 3u * P : 0u), bs, L.samples_per_pixel, color, fold);
                     bdone = true;
                 } else {
                     cont = true;
