@@ -171,11 +171,11 @@ void or32_show_random(uint32_t width, uint32_t height, uint64_t seed, int norm, 
             for (int k = 0; k < 3; k++) rgb[k] = or_u01(or_pcg32_next(&st, inc));
         } else {     /* random_norm_float3, library.cu:25-31, with the rejection sampler used by the renderer */
             rgb[0] = 1.0f; rgb[1] = 0.0f; rgb[2] = 0.0f;
-            for (int i = 0; i < 20; i++) { /* one try = two outputs cut into three 21-bit coordinates */
-                uint32_t a = or_pcg32_next(&st, inc), b = or_pcg32_next(&st, inc);
-                float x = fmaf((float)(a >> 11), 0x1p-20f, -1.0f);
-                float y = fmaf((float)(b >> 11), 0x1p-20f, -1.0f);
-                float z = fmaf((float)(((a & 0x7ffu) << 10) | (b & 0x3ffu)), 0x1p-20f, -1.0f);
+            for (int i = 0; i < 20; i++) { /* one try = one output cut into 11 + 11 + 10 bits, as in or32_random_unit_vector */
+                uint32_t a = or_pcg32_next(&st, inc);
+                float x = fmaf((float)(a >> 21), 0x1p-10f, -1.0f + 0x1p-11f);
+                float y = fmaf((float)((a >> 10) & 0x7ffu), 0x1p-10f, -1.0f + 0x1p-11f);
+                float z = fmaf((float)(a & 0x3ffu), 0x1p-9f, -1.0f + 0x1p-10f);
                 float d = fmaf(z, z, fmaf(y, y, x * x));
                 if (d <= 1.0f) {
                     float inv = 1.0f / sqrtf(d);

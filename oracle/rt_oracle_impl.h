@@ -53,17 +53,17 @@ static inline V3 NAME(ld3f)(const float *p) { return NAME(v3)(R(p[0]), R(p[1]), 
 typedef struct { uint64_t state, inc; } NAME(Rng);
 static inline REAL NAME(rand01)(NAME(Rng) *g) { return R(or_u01(or_pcg32_next(&g->state, g->inc))); }
 
-/* random_unit_vector: rejection in [-1,1)^3, accept p.p <= 1, normalise (lib.rs:31-47), with the
- * GPU path's bound of 20 tries and its (1,0,0) fallback (library.cu:25-31).  One try takes two generator
- * outputs a, b and cuts three 21-bit coordinates out of their 64 bits: x = a >> 11, y = b >> 11,
- * z = (a & 0x7ff) << 10 | (b & 0x3ff); a coordinate is k * 2^-20 - 1 (exact in single precision). */
+/* random_unit_vector: rejection in (-1,1)^3, accept p.p <= 1, normalise (lib.rs:31-47), with the
+ * GPU path's bound of 20 tries and its (1,0,0) fallback (library.cu:25-31).  One try takes ONE generator
+ * output a and cuts three coordinates out of its 32 bits: x = a >> 21 and y = (a >> 10) & 0x7ff (11 bits each,
+ * value (k + 1/2) 2^-10 - 1), z = a & 0x3ff (10 bits, (k + 1/2) 2^-9 - 1): cell centres of a regular grid over the
+ * cube, symmetric about the origin, never the zero vector; every value is exact in single precision. */
 static inline V3 NAME(random_unit_vector)(NAME(Rng) *g) {
     for (int i = 0; i < 20; i++) {
         uint32_t a = or_pcg32_next(&g->state, g->inc);
-        uint32_t b = or_pcg32_next(&g->state, g->inc);
-        REAL x = MADD(R(a >> 11), R(0x1p-20), R(-1));
-        REAL y = MADD(R(b >> 11), R(0x1p-20), R(-1));
-        REAL z = MADD(R(((a & 0x7ffu) << 10) | (b & 0x3ffu)), R(0x1p-20), R(-1));
+        REAL x = MADD(R(a >> 21), R(0x1p-10), R(-1 + 0x1p-11));
+        REAL y = MADD(R((a >> 10) & 0x7ffu), R(0x1p-10), R(-1 + 0x1p-11));
+        REAL z = MADD(R(a & 0x3ffu), R(0x1p-9), R(-1 + 0x1p-10));
         V3 p = NAME(v3)(x, y, z);
         if (NAME(dot)(p, p) <= R(1)) return NAME(unit)(p);
     }

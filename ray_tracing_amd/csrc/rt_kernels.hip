@@ -94,20 +94,22 @@ RT_DEV Rng stream_init(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t 
 // top 24 bits -> [0,1), exact (the reference's ldexpf(u,-32), library.cu:18-24, can round to 1.0)
 RT_DEV float rand01(Rng& g) { return (float)(pcg_next(g) >> 8) * 0x1p-24f; }
 
-// Rejection in [-1,1)^3, accept p.p <= 1, normalise (lib.rs:31-47); at most 20 tries, then (1,0,0)
-// (library.cu:25-31).  One try takes two generator outputs a, b and cuts three 21-bit coordinates out of their
-// 64 bits: x = a >> 11, y = b >> 11, z = (a & 0x7ff) << 10 | (b & 0x3ff); a coordinate is k * 2^-20 - 1, exact.
-// (Two 64-bit multiplies per try instead of three: integer multiplies run at a quarter of the fp32 rate.)
+// Rejection in (-1,1)^3, accept p.p <= 1, normalise (lib.rs:31-47); at most 20 tries, then (1,0,0)
+// (library.cu:25-31).  One try takes ONE generator output a and cuts three coordinates out of its 32 bits:
+// x = a >> 21 and y = (a >> 10) & 0x7ff (11 bits, value (k + 1/2) 2^-10 - 1), z = a & 0x3ff (10 bits,
+// (k + 1/2) 2^-9 - 1): cell centres of a regular grid over the cube, symmetric about the origin and never the zero
+// vector; all exact.  (One 64-bit multiply per try: integer multiplies run at a quarter of the fp32 rate, and the
+// lanes of a wavefront wait for the one with the most tries.)
 RT_DEV V3 random_unit_vector(Rng& g, Stats& st) {
     V3 p = v3(1.0f, 0.0f, 0.0f);
     bool done = false;
     for (int i = 0; i < 20 && !done; i++) {
         st.add(5, 1u);
         st.wave(7);
-        const uint32_t a = pcg_next(g), b = pcg_next(g);
-        float x = fmaf((float)(a >> 11), 0x1p-20f, -1.0f);
-        float y = fmaf((float)(b >> 11), 0x1p-20f, -1.0f);
-        float z = fmaf((float)(((a & 0x7ffu) << 10) | (b & 0x3ffu)), 0x1p-20f, -1.0f);
+        const uint32_t a = pcg_next(g);
+        float x = fmaf((float)(a >> 21), 0x1p-10f, -1.0f + 0x1p-11f);
+        float y = fmaf((float)((a >> 10) & 0x7ffu), 0x1p-10f, -1.0f + 0x1p-11f);
+        float z = fmaf((float)(a & 0x3ffu), 0x1p-9f, -1.0f + 0x1p-10f);
         V3 q = v3(x, y, z);
         if (vdot(q, q) <= 1.0f) { p = q; done = true; }
     }

@@ -297,7 +297,7 @@ def test_lambertian_direction_and_near_zero_guard(oracle):
 
 def test_unit_vector_sampler_is_uniform_on_the_sphere(oracle):
     """Rejection in the cube, accept p.p <= 1, normalise (lib.rs:31-47): unit length, zero mean, second moments
-    1/3 on the diagonal and 0 off it, and the third coordinate (cut from the low bits of both generator outputs)
+    1/3 on the diagonal and 0 off it, and the third coordinate (the 10 low bits of the generator output, the others 11 bits each)
     uncorrelated with the other two."""
     v = np.array([oracle.unit_vector((77, p, s, 1)) for p in range(200) for s in range(100)])
     assert np.allclose(np.linalg.norm(v, axis=1), 1.0, atol=1e-12)
