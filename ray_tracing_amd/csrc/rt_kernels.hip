@@ -227,7 +227,7 @@ RT_DEV float filter_inv_len(float a) { return __builtin_amdgcn_rsqf(a) * (1.0f +
 // minus squared distance from the centre to the ray's line).  Expanded around a scene-wide translation T
 // (c' = c - T per sphere at upload, o' = o - T per ray) this is, per sphere and lane,
 //   t = k0 + w.c'         (3 fma)   w = 2 o',  k0 = -|o'|^2 (1-2^-18)                   [per ray]
-//   g = e + uf.c'         (3 fma)   uf = d (1/sqrt(d.d)) (1+2^-19),  e = -uf.o'         [per ray]
+//   g = e + uf.c'         (3 fma)   uf = d rsq(d.d) (1+2^-19),  e = -uf.o'              [per ray]
 //   q = g*g + t           (1 fma)
 //   key = q + m           (1 add)   m = r*r(1+2^-17) - |c'|^2 (1-2^-18)                 [per sphere, upload]
 // 8 VALU operations, +1 to record the sign of key: 9 per sphere, no branch, no compare, no subtraction

@@ -2,7 +2,9 @@
 
 Kernel (rt_kernels.hip, scan_tile), with T the scene translation, c' = fl(c - T), o' = fl(o - T):
   t = fma(w.z,c'z, fma(w.y,c'y, fma(w.x,c'x, k0)))     w = 2 o',  k0 = -(o'.o' (1-2^-18))
-  g = fma(uf.z,c'z, fma(uf.y,c'y, fma(uf.x,c'x, e)))   uf = d (1/sqrt(d.d)) (1+2^-19),  e = -uf.o'
+  g = fma(uf.z,c'z, fma(uf.y,c'y, fma(uf.x,c'x, e)))   uf = d rsq(d.d) (1+2^-19),  e = -uf.o'
+                                                       rsq = the hardware's 1/sqrt, accurate to 1 ulp: modelled here as the
+                                                       correctly rounded value and its two neighbours (all three are checked)
   key = fma(g, g, t) + m                               m = r*r(1+2^-17) - |c'|^2 (1-2^-18), rounded up;
   candidate iff sign(key) clear.
 Exact test (checker order):  disc = fma(h, h, a*ncc),  h = d.oc,  ncc = r*r - oc.oc, oc = c - o;  needs disc >= 0.
@@ -34,12 +36,15 @@ def terms(o, d, c, rr):
     return oc, a, h, ncc, disc
 
 
-def filt(o, d, c, rr, a, T):
+def filt(o, d, c, rr, a, T, rsq_ulp=0):
     cp = [(c[k].astype(np.float64) - np.float64(T[k])).astype(f32) for k in range(3)]       # upload, in double
     cc = sum(cp[k].astype(np.float64) ** 2 for k in range(3))
     m = np.nextafter((rr.astype(np.float64) * (1.0 + 2.0 ** -17) - cc * (1.0 - 2.0 ** -18)).astype(f32), f32(np.inf))
     op = [(o[k] - f32(T[k])).astype(f32) for k in range(3)]                                 # kernel, per ray
-    inv = ((f32(1.0) / np.sqrt(a)).astype(f32) * f32(1.0 + 2.0 ** -19)).astype(f32)
+    rsq = (1.0 / np.sqrt(a.astype(np.float64))).astype(f32)                                 # v_rsq_f32: within 1 ulp of this
+    if rsq_ulp:
+        rsq = np.nextafter(rsq, f32(np.inf) if rsq_ulp > 0 else f32(0.0))
+    inv = (rsq * f32(1.0 + 2.0 ** -19)).astype(f32)
     uf = [(d[k] * inv).astype(f32) for k in range(3)]
     e = -dot(uf, op)
     w = [(f32(2.0) * op[k]).astype(f32) for k in range(3)]
@@ -56,12 +61,14 @@ def check(o, d, c, r, label, T=(0.0, 0.0, 0.0)):
     c = [x.astype(f32) for x in c]
     rr = (r.astype(f32) * r.astype(f32)).astype(f32)
     oc, a, h, ncc, disc = terms(o, d, c, rr)
-    q, q5 = filt(o, d, c, rr, a, [f32(x) for x in T])
     accepted = disc >= 0
     assert accepted.sum() > 0, label
-    for form, key in (("scan_tile", q), ("scan_primary", q5)):
-        dropped = accepted & np.signbit(key)
-        assert not dropped.any(), f"{label}: {dropped.sum()} exact-test candidates dropped by the {form} filter"
+    for rsq_ulp in (-1, 0, 1):
+        q, q5 = filt(o, d, c, rr, a, [f32(x) for x in T], rsq_ulp)
+        for form, key in (("scan_tile", q), ("scan_primary", q5)):
+            dropped = accepted & np.signbit(key)
+            assert not dropped.any(), (f"{label}: {dropped.sum()} exact-test candidates dropped by the {form} filter "
+                                       f"(1/sqrt off by {rsq_ulp} ulp)")
     return accepted.mean()
 
 
