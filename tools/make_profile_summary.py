@@ -51,9 +51,17 @@ w(f"bench.py in the same run: kernel_ms {bench['roofline']['kernel_ms']:.1f} (HI
   f"({bench['roofline']['flop_per_segment']} FLOP per segment)")
 w(f"dispatch: {meta}")
 waves = int(meta.get("Grid_Size", 0)) // 64 if meta else 0
+# registers the compiler allotted: from the code object's metadata in the ISA listing (make -C ray_tracing_amd/csrc asm)
+vgprs = None
+asm = os.path.join(root, "ray_tracing_amd", "csrc", "rt_kernels.s")
+if os.path.exists(asm):
+    text = open(asm).read()
+    m = re.search(r"\.name:\s+" + re.escape(KERNEL) + r"\n(?:.*\n)*?\s+\.vgpr_count:\s+(\d+)", text)
+    vgprs = int(m.group(1)) if m else None
 w(f"  launched: Grid_Size / 64 = {waves} wavefronts.  rocprofv3's VGPR_Count is half of what the compiler reports for the same kernel")
-w("  (hipcc -Rpass-analysis=kernel-resource-usage: rt_render_queue 96 VGPRs, which is what 5 waves per SIMD of a 512-register file")
-w("  allow and what the measured residency below confirms; the dispatch row divides the descriptor's 8-register granules by two).")
+w(f"  (code object metadata: {KERNEL} .vgpr_count {vgprs}, allocated in granules of 8 -> {((vgprs + 7) // 8 * 8) if vgprs else '?'}, within the 96 that 5 waves per SIMD")
+w("  of a 512-register file allow and that the measured residency below confirms; the dispatch row divides the descriptor's")
+w("  8-register granules by two).")
 if pmc.get("SQ_WAVES") and waves:
     w(f"  SQ_WAVES reads {pmc['SQ_WAVES']:.0f} = {pmc['SQ_WAVES'] / waves:.2f} x the wavefronts launched.")
 w("")
