@@ -39,9 +39,10 @@ struct rt_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipModule_t module = nullptr;
-    hipFunction_t f_render = nullptr, f_render_queue = nullptr, f_render_queue_fold = nullptr, f_render_queue_stream_fold = nullptr, f_render_stream = nullptr, f_render_queue_stream = nullptr, f_hits = nullptr, f_random = nullptr, f_assemble = nullptr;
+    hipFunction_t f_render = nullptr, f_render_queue = nullptr, f_render_queue_fold = nullptr, f_render_queue_stream_fold = nullptr, f_render_stream = nullptr, f_render_queue_stream = nullptr, f_hits = nullptr, f_random = nullptr, f_assemble = nullptr, f_camera_terms = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     void *d_geom = nullptr, *d_exact = nullptr, *d_shade = nullptr, *d_mat = nullptr;
+    void* d_camterms = nullptr;         // per sphere {A, B, C, sq} of the camera-ray scan, rewritten by every launch (rt_camera_terms)
     float translate[3] = {0.0f, 0.0f, 0.0f};
     uint32_t n_spheres = 0, n_padded = 0;
     bool have_scene = false;
@@ -105,7 +106,7 @@ int ensure(rt_ctx* c, void** p, size_t* cap, size_t bytes) {
 int load_image(rt_ctx* c, const void* image) {
     hipModule_t m = nullptr;
     RT_HIP(c, hipModuleLoadData(&m, image));
-    hipFunction_t fr, fq, fs, fqs, fh, fx, fa, fqf, fqsf;
+    hipFunction_t fr, fq, fs, fqs, fh, fx, fa, fqf, fqsf, fct;
     hipError_t e;
     if ((e = hipModuleGetFunction(&fr, m, "rt_render")) != hipSuccess ||
         (e = hipModuleGetFunction(&fq, m, "rt_render_queue")) != hipSuccess ||
@@ -115,6 +116,7 @@ int load_image(rt_ctx* c, const void* image) {
         (e = hipModuleGetFunction(&fs, m, "rt_render_stream")) != hipSuccess ||
         (e = hipModuleGetFunction(&fh, m, "rt_primary_hits")) != hipSuccess ||
         (e = hipModuleGetFunction(&fx, m, "rt_show_random")) != hipSuccess ||
+        (e = hipModuleGetFunction(&fct, m, "rt_camera_terms")) != hipSuccess ||
         (e = hipModuleGetFunction(&fa, m, "rt_assemble")) != hipSuccess) {
         (void)hipModuleUnload(m);
         return hip_fail(c, e, "hipModuleGetFunction");
@@ -150,7 +152,7 @@ int load_image(rt_ctx* c, const void* image) {
     c->counter_need = need;
     if (c->module) (void)hipModuleUnload(c->module);
     c->module = m;
-    c->f_render_queue_fold = fqf; c->f_render_queue_stream_fold = fqsf; c->f_render = fr; c->f_render_queue = fq; c->f_render_queue_stream = fqs; c->f_render_stream = fs; c->f_hits = fh; c->f_random = fx; c->f_assemble = fa;
+    c->f_render_queue_fold = fqf; c->f_render_queue_stream_fold = fqsf; c->f_render = fr; c->f_render_queue = fq; c->f_render_queue_stream = fqs; c->f_render_stream = fs; c->f_hits = fh; c->f_random = fx; c->f_assemble = fa; c->f_camera_terms = fct;
     return 0;
 }
 
@@ -307,8 +309,13 @@ int launch_render(rt_ctx* c, const RtCamera* cam, const RtParams* p, RtLaunch L,
     void* d_work = static_cast<char*>(counters) + 64;
     RT_HIP(c, hipMemsetAsync(counters, 0, c->counter_need, c->stream));
     RtCamera cam_copy = *cam;
-    void* args[] = {&c->d_geom, &c->d_exact, &c->d_shade, &c->d_mat, &d_rgba, &d_linear, &d_count, &d_work, &d_fold, &cam_copy, &L};
+    void* args[] = {&c->d_geom, &c->d_exact, &c->d_shade, &c->d_mat, &d_rgba, &d_linear, &d_count, &d_work, &d_fold, &c->d_camterms, &cam_copy, &L};
     RT_HIP(c, hipEventRecord(c->ev0, c->stream));
+    if (grid > 0 && queue) {
+        // the camera-ray scan's four numbers per sphere for this camera (inside the timed region: part of the frame)
+        void* targs[] = {&c->d_exact, &c->d_camterms, &cam_copy, &L};
+        RT_HIP(c, hipModuleLaunchKernel(c->f_camera_terms, (c->n_padded + 255u) / 256u, 1, 1, 256, 1, 1, 0, c->stream, targs, nullptr));
+    }
     if (grid > 0)
         RT_HIP(c, hipModuleLaunchKernel(f, grid, 1, 1, block, 1, 1, lds, c->stream, args, nullptr));
     RT_HIP(c, hipEventRecord(c->ev1, c->stream));
@@ -458,7 +465,7 @@ void rt_destroy(rt_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->comm && rccl()->CommDestroy) (void)rccl()->CommDestroy(c->comm);
-    void* bufs[] = {c->d_geom, c->d_exact, c->d_shade, c->d_mat, c->d_rgba, c->d_linear, c->d_hits, c->d_counter, c->d_tiles, c->d_frame, c->d_status, c->d_fold};
+    void* bufs[] = {c->d_geom, c->d_exact, c->d_shade, c->d_mat, c->d_camterms, c->d_rgba, c->d_linear, c->d_hits, c->d_counter, c->d_tiles, c->d_frame, c->d_status, c->d_fold};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -542,13 +549,14 @@ int rt_upload_scene(rt_ctx* c, const RtSphere* spheres, uint32_t n) {
         }
     }
     size_t bytes = (size_t)n_padded * 16u;
-    void** owned[] = {&c->d_geom, &c->d_exact, &c->d_shade, &c->d_mat};
+    void** owned[] = {&c->d_geom, &c->d_exact, &c->d_shade, &c->d_mat, &c->d_camterms};
     for (void** p : owned) if (*p) { RT_HIP(c, hipFree(*p)); *p = nullptr; }
     c->have_scene = false;
     RT_HIP(c, hipMalloc(&c->d_geom, bytes));
     RT_HIP(c, hipMalloc(&c->d_exact, bytes));
     RT_HIP(c, hipMalloc(&c->d_shade, 3 * bytes));
     RT_HIP(c, hipMalloc(&c->d_mat, (size_t)n_padded * 4u));
+    RT_HIP(c, hipMalloc(&c->d_camterms, bytes));
     RT_HIP(c, hipMemcpy(c->d_geom, geom.data(), bytes, hipMemcpyHostToDevice));
     RT_HIP(c, hipMemcpy(c->d_exact, exact.data(), bytes, hipMemcpyHostToDevice));
     RT_HIP(c, hipMemcpy(c->d_shade, shade.data(), 3 * bytes, hipMemcpyHostToDevice));

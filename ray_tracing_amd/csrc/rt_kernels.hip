@@ -6,6 +6,7 @@
 //   rt_render_queue_fold, rt_render_queue_stream_fold   the same two, adding each pixel's samples in sample order
 //   rt_render               work items of `chunk` samples, or one lane per pixel in the reference's fold order
 //   rt_render_stream        the same for longer sphere lists
+// and rt_camera_terms runs before the first four: the camera-ray scan's four numbers per sphere for the launch's camera.
 // Built with
 //   hipcc --offload-arch=gfx950 --genco -O3 -ffp-contract=off
 // and loaded with hipModuleLoadData by rt_hip.cpp.  No MFMA: the work is divergent scalar fp32.
@@ -287,27 +288,33 @@ RT_DEV void scan_tile(const Tile& tile, uint32_t count, int base, V3 T,
     st.lap(11);
 }
 
-// The scan for camera rays.  They all leave from the camera centre, so the origin-dependent half of the
-// filter, t + m = k0 + w.c' + m, is one number per sphere for the whole launch (computed when the tile is staged,
-// with the operations of scan_tile, and kept as the fourth word of a second copy of the filter data: one
-// 16-byte LDS read per sphere, as in scan_tile) and the scan is g (3 fma), key = fma(g, g, t + m) (1) and the sign
-// bit (1): 5 operations per sphere and lane instead of 9.  One rounding moves from the end of the chain to
-// that number; the bound of scan_tile's derivation and its slack are unchanged.
-RT_DEV void scan_primary(const float4* __restrict__ geo0, const Tile& tile, uint32_t count, int base, V3 T,
-                         V3 o, V3 d, float a, float t_min, Best& b, Cand& c, Stats& st) {
+// The scan for camera rays.  They all leave from the camera centre o, and their directions are an affine function
+// of the image coordinates: d = P0 + fx du + fy dv (P0 = pixel00 - o; make_ray).  With q = c - o the filter's
+// condition  r*r - |q|^2 + (u.q)^2 >= 0  reads  |d.q| / |d| >= sqrt(|q|^2 - r*r),  and d.q = C + fx A + fy B with
+// three numbers per sphere, A = du.q, B = dv.q, C = P0.q.  rt_camera_terms (below) computes them once per launch, in
+// double precision, together with the right-hand side: per sphere {A, B, C, sq} in one 16-byte LDS read, and the
+// scan is  dq = fma(fx, A, fma(fy, B, C));  key = fma(|dq|, iLs, -sq)  and the sign bit: 4 operations per sphere
+// and lane (|.| is a source modifier), against 9 for a ray with an origin of its own.  Slack (so that the exact
+// test's  disc >= 0  implies  key >= 0):  iLs = rsq(d.d)(1 + 2^-19);  sq = sqrt(|q|^2 (1-2^-18) - r*r (1+2^-17))
+// (1 - 2^-20) - s_abs, rounded down, with the same two inflations as scan_tile for the difference between the
+// filter's condition and the exact test's own roundings, and s_abs for this form's: 4 * 2^-24 M / F for the
+// roundings of A, B, C and the two fma (M = |C| + (W+1)|A| + (H+1)|B| bounds every partial sum, F = the distance
+// from o to the image plane <= |d|; fx and fy are the very numbers make_ray uses), 2 |q| eta / F for the difference
+// in direction and in length between P0 + fx du + fy dv and make_ray's rounded d (eta: see rt_camera_terms), and
+// 2^-22 |q| for the last fma.  A camera inside the inflated sphere (or a NaN) gives sq = -inf: always a candidate;
+// padding gives sq = +inf: never.
+RT_DEV void scan_primary(const float4* __restrict__ geo0, const Tile& tile, uint32_t count, int base,
+                         float fx, float fy, V3 o, V3 d, float a, float t_min, Best& b, Cand& c, Stats& st) {
     st.wave(0);
-    const V3 op = vsub(o, T);
-    const float inv_len = filter_inv_len(a);
-    const V3 uf = v3(d.x * inv_len, d.y * inv_len, d.z * inv_len);
-    const float e = -vdot(uf, op);
+    const float iLs = filter_inv_len(a);
     auto step8 = [&](const float4* p8, uint32_t& miss) {
         float4 s[RT_SCAN_UNROLL];
 #pragma unroll
         for (uint32_t u = 0; u < RT_SCAN_UNROLL; u++) s[u] = p8[u];
 #pragma unroll
         for (uint32_t u = 0; u < RT_SCAN_UNROLL; u++) {
-            const float g = fmaf(uf.z, s[u].z, fmaf(uf.y, s[u].y, fmaf(uf.x, s[u].x, e)));
-            const float key = fmaf(g, g, s[u].w);
+            const float dq = fmaf(fx, s[u].x, fmaf(fy, s[u].y, s[u].z));
+            const float key = fmaf(fabsf(dq), iLs, -s[u].w);
             miss = __builtin_amdgcn_alignbit(miss, __float_as_uint(key), 31u);
         }
     };
@@ -433,8 +440,9 @@ RT_DEV V3 scatter(uint32_t mat, float param, const float4* __restrict__ glass_te
 }
 
 // Primary ray of pixel (i,j) with sub-pixel offset (si,sj): ray.cu:62-77 / lib.rs:215-217.
-RT_DEV void make_ray(const RtCamera& cam, uint32_t i, uint32_t j, float si, float sj, V3& o, V3& d) {
-    float fx = (float)i + si, fy = (float)j + sj;
+RT_DEV void make_ray(const RtCamera& cam, uint32_t i, uint32_t j, float si, float sj, V3& o, V3& d, float& fx, float& fy) {
+    fx = (float)i + si;
+    fy = (float)j + sj;
     V3 pc;
     pc.x = cam.pixel00_loc[0] + fmaf(cam.pixel_delta_u[0], fx, cam.pixel_delta_v[0] * fy);
     pc.y = cam.pixel00_loc[1] + fmaf(cam.pixel_delta_u[1], fx, cam.pixel_delta_v[1] * fy);
@@ -444,7 +452,7 @@ RT_DEV void make_ray(const RtCamera& cam, uint32_t i, uint32_t j, float si, floa
 }
 
 RT_DEV void sample_ray(const RtCamera& cam, const RtLaunch& L, uint64_t seed, uint32_t x, uint32_t y,
-                       uint32_t pixel, uint32_t s, V3& o, V3& d) {
+                       uint32_t pixel, uint32_t s, V3& o, V3& d, float& fx, float& fy) {
     float si, sj;
     if (L.flags & RT_FLAG_SAMPLER_GRID) {                        // ray.cu:59-60
         uint32_t n2 = L.sample2_per_pixel;
@@ -455,7 +463,7 @@ RT_DEV void sample_ray(const RtCamera& cam, const RtLaunch& L, uint64_t seed, ui
         si = rand01(g) - 0.5f;
         sj = rand01(g) - 0.5f;
     }
-    make_ray(cam, x, y, si, sj, o, d);
+    make_ray(cam, x, y, si, sj, o, d, fx, fy);
 }
 
 RT_DEV uint32_t quant(float lin, uint32_t flags) {
@@ -709,7 +717,8 @@ RT_DEV void render_body(const Scene& sc, uint32_t* __restrict__ rgba, float4* __
         }
         // one place generates camera rays: for the first sample of a new item and for the next sample of a running one
         if (new_path) {
-            sample_ray(cam, L, seed, it.x, it.y, it.pixel, it.s, o, d);
+            float fx_unused, fy_unused;
+            sample_ray(cam, L, seed, it.x, it.y, it.pixel, it.s, o, d, fx_unused, fy_unused);
             new_path = false;
         }
         st.lap(14);
@@ -820,12 +829,12 @@ RT_DEV void render_body(const Scene& sc, uint32_t* __restrict__ rgba, float4* __
 // ---------------------------------------------------------------- render, camera rays traced in batches
 // Used when every sample is its own work item (sample_chunk = 1) and the sphere list fits the LDS tile.
 // A third of all path segments are camera rays, and those share their origin: the wavefront traces them 64
-// at a time with scan_primary (5 operations per sphere instead of 9, every lane busy), shades them on the
+// at a time with scan_primary (4 operations per sphere instead of 9, every lane busy), shades them on the
 // spot -- a miss is a finished sample and goes straight to the pixel's accumulator -- and queues the
 // scattered rays of the hits in LDS.  The loop of render_body then runs on bounce segments only: a lane
 // whose path has ended takes the next queued ray; when the queue is empty the next batch of camera rays
 // of the unit is traced.  Image and segment count are those of render_body with sample_chunk = 1, bit for bit.
-//   LDS: [geo S float4][geo0 S float4] then per wavefront
+//   LDS: [geo S float4][geo0 S float4: this launch's camera-ray terms, see rt_camera_terms] then per wavefront
 //        [candidate lists RT_Q_CAND_CAP x 64 u16][accumulators 2 x P x 3 u64][queue RT_Q_WORDS x 64 u32]
 // RT_Q_WORDS (rt_device.h) = 8 words per queued ray: origin xyz, direction xyz, sample,
 // (slot * 64 + pixel of unit) << 16 | sphere hit
@@ -944,7 +953,8 @@ RT_DEV void primary_batch(const Scene& sc, const Tile& tile, const float4* __res
     if (traced) {
         const uint32_t pixel = y * L.width + x;
         const float band = (L.flags & RT_FLAG_BAND_ALBEDO) ? band_of(L, x) : 0.0f;
-        sample_ray(cam, L, seed, x, y, pixel, s, p.o, p.d);
+        float fx, fy;
+        sample_ray(cam, L, seed, x, y, pixel, s, p.o, p.d, fx, fy);
         p.thr = v3(1.0f, 1.0f, 1.0f);
         p.seg = 0u;
         p.nb = 0u;
@@ -952,9 +962,9 @@ RT_DEV void primary_batch(const Scene& sc, const Tile& tile, const float4* __res
         b.t = L.t_max;
         b.idx = -1;
         st.lap(14);
-        scan_primary(geo0, tile, L.n_padded, 0, T, p.o, p.d, vdot(p.d, p.d), L.t_min, b, cand, st);
+        scan_primary(geo0, tile, L.n_padded, 0, fx, fy, p.o, p.d, vdot(p.d, p.d), L.t_min, b, cand, st);
 #ifdef RT_EXP_PRIMARY2
-        scan_primary(geo0, tile, L.n_padded, 0, T, p.o, p.d, vdot(p.d, p.d), L.t_min, b, cand, st);   // cost experiment: changes nothing (strict bound)
+        scan_primary(geo0, tile, L.n_padded, 0, fx, fy, p.o, p.d, vdot(p.d, p.d), L.t_min, b, cand, st);   // cost experiment: changes nothing (strict bound)
 #endif
         nseg++;
         sphere = (uint32_t)b.idx;
@@ -973,7 +983,8 @@ RT_DEV void primary_batch(const Scene& sc, const Tile& tile, const float4* __res
 template <bool FOLD>
 RT_DEV void render_queue_body(const Scene& sc, uint32_t* __restrict__ rgba, float4* __restrict__ linear,
                               unsigned long long* __restrict__ segments, uint32_t* __restrict__ work,
-                              float4* __restrict__ fold_all, const RtCamera& cam, const RtLaunch& L) {
+                              float4* __restrict__ fold_all, const float4* __restrict__ camterms, const RtCamera& cam,
+                              const RtLaunch& L) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform: kept in a scalar register
     const uint64_t seed = ((uint64_t)L.seed_hi << 32) | L.seed_lo;
@@ -996,17 +1007,12 @@ RT_DEV void render_queue_body(const Scene& sc, uint32_t* __restrict__ rgba, floa
     // fold-order mode: this wavefront's [2 slots][P][samples_per_pixel] colours in the launch's workspace
     float4* fold = FOLD ? fold_all + (size_t)(blockIdx.x * (blockDim.x >> 6) + wave) * (2u * P * (size_t)L.samples_per_pixel) : nullptr;
     const float4* fold1 = FOLD ? fold + (size_t)P * L.samples_per_pixel : nullptr;
-    {   // stage the spheres; geo0.w = t + m with the operations of scan_tile for the camera centre as origin
-        const V3 op = vsub(ld3(cam.center), T);
-        const V3 w = v3(2.0f * op.x, 2.0f * op.y, 2.0f * op.z);
-        const float k0 = -(vdot(op, op) * (1.0f - 0x1p-18f));
-        for (uint32_t i = threadIdx.x; i < S; i += blockDim.x) {
-            const float4 c = sc.geom[i];
-            geo[i] = c;
-            geo0[i] = make_float4(c.x, c.y, c.z, fmaf(w.z, c.z, fmaf(w.y, c.y, fmaf(w.x, c.x, k0))) + c.w);
-        }
-        __syncthreads();
+    // stage the spheres: the filter data of scan_tile and the camera-ray terms of this launch (rt_camera_terms)
+    for (uint32_t i = threadIdx.x; i < S; i += blockDim.x) {
+        geo[i] = sc.geom[i];
+        geo0[i] = camterms[i];
     }
+    __syncthreads();
     // the exact-test data stays in global memory (8 KB, read a couple of times per ray, cached): with it in LDS
     // a compute unit holds four workgroups instead of five, measured 2 % slower on the 485-sphere scene
     const Tile tile = {geo, sc.exact};
@@ -1127,7 +1133,8 @@ RT_DEV void render_queue_body(const Scene& sc, uint32_t* __restrict__ rgba, floa
 template <bool FOLD>
 RT_DEV void render_queue_stream_body(const Scene& sc, uint32_t* __restrict__ rgba, float4* __restrict__ linear,
                                      unsigned long long* __restrict__ segments, uint32_t* __restrict__ work,
-                                     float4* __restrict__ fold_all, const RtCamera& cam, const RtLaunch& L) {
+                                     float4* __restrict__ fold_all, const float4* __restrict__ camterms,
+                                     const RtCamera& cam, const RtLaunch& L) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform: kept in a scalar register
     const uint64_t seed = ((uint64_t)L.seed_hi << 32) | L.seed_lo;
@@ -1149,10 +1156,6 @@ RT_DEV void render_queue_stream_body(const Scene& sc, uint32_t* __restrict__ rgb
     for (uint32_t k = lane; k < 6u * P; k += 64u) accum[k] = 0ull;
     float4* fold = FOLD ? fold_all + (size_t)(blockIdx.x * (blockDim.x >> 6) + wave) * (2u * P * (size_t)L.samples_per_pixel) : nullptr;
     const float4* fold1 = FOLD ? fold + (size_t)P * L.samples_per_pixel : nullptr;
-    // camera-centre constants of geo0.w = t + m (operations of scan_tile)
-    const V3 op0 = vsub(ld3(cam.center), T);
-    const V3 w0 = v3(2.0f * op0.x, 2.0f * op0.y, 2.0f * op0.z);
-    const float k00 = -(vdot(op0, op0) * (1.0f - 0x1p-18f));
 
     Stats st;
     Slot u0, u1;
@@ -1212,6 +1215,7 @@ RT_DEV void render_queue_stream_body(const Scene& sc, uint32_t* __restrict__ rgb
         bool bdone = false, traced = false;
         Path bp;
         bp.o = bp.d = v3(0.0f, 0.0f, 0.0f); bp.thr = v3(1.0f, 1.0f, 1.0f); bp.seg = 0u; bp.nb = 0u;
+        float bfx = 0.0f, bfy = 0.0f;                            // image coordinates of the camera ray
         if (primary) {
             const uint32_t sidx = next_samp + lane;
             bpix = sidx & (P - 1u);
@@ -1224,7 +1228,7 @@ RT_DEV void render_queue_stream_body(const Scene& sc, uint32_t* __restrict__ rgb
             if (traced) {
                 bpixel = y * L.width + x;
                 if (flags & RT_FLAG_BAND_ALBEDO) bband = band_of(L, x);
-                sample_ray(cam, L, seed, x, y, bpixel, bs, bp.o, bp.d);
+                sample_ray(cam, L, seed, x, y, bpixel, bs, bp.o, bp.d, bfx, bfy);
             }
         }
         const bool scanning = primary ? traced : active;
@@ -1238,16 +1242,15 @@ RT_DEV void render_queue_stream_body(const Scene& sc, uint32_t* __restrict__ rgb
             if (count > RT_Q_STREAM_TILE) count = RT_Q_STREAM_TILE;
             if (first) __syncthreads();                          // previous tile fully scanned
             for (uint32_t i = threadIdx.x; i < count; i += blockDim.x) {
-                const float4 c = sc.geom[first + i];
-                geo[i] = c;
-                geo0[i] = make_float4(c.x, c.y, c.z, fmaf(w0.z, c.z, fmaf(w0.y, c.y, fmaf(w0.x, c.x, k00))) + c.w);
+                geo[i] = sc.geom[first + i];
+                geo0[i] = camterms[first + i];
             }
             __syncthreads();
             const Tile tile = {geo, sc.exact + first};           // exact-test data from global memory
             if (scanning) {
-                if (primary) scan_primary(geo0, tile, count, (int)first, T, ro, rd, ra, L.t_min, b, cand, st);
+                if (primary) scan_primary(geo0, tile, count, (int)first, bfx, bfy, ro, rd, ra, L.t_min, b, cand, st);
 #ifdef RT_EXP_PRIMARY2
-                if (primary) scan_primary(geo0, tile, count, (int)first, T, ro, rd, ra, L.t_min, b, cand, st);   // cost experiment
+                if (primary) scan_primary(geo0, tile, count, (int)first, bfx, bfy, ro, rd, ra, L.t_min, b, cand, st);   // cost experiment
 #endif
                 else scan_tile(tile, count, (int)first, T, ro, rd, ra, L.t_min, b, cand, st);
             }
@@ -1300,23 +1303,26 @@ RT_DEV void render_queue_stream_body(const Scene& sc, uint32_t* __restrict__ rgb
 
 extern "C" __global__ void __launch_bounds__(1024)
 rt_render(const float4* geom, const float4* exact, const float4* shade, const uint32_t* mat, uint32_t* rgba,
-          float4* linear, unsigned long long* segments, uint32_t* work, float4* fold, RtCamera cam, RtLaunch L) {
+          float4* linear, unsigned long long* segments, uint32_t* work, float4* fold, const float4* camterms,
+          RtCamera cam, RtLaunch L) {
     Scene sc = {geom, exact, shade, mat};
     render_body<false>(sc, rgba, linear, segments, work, cam, L);
 }
 
 extern "C" __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(5)))
 rt_render_queue(const float4* geom, const float4* exact, const float4* shade, const uint32_t* mat, uint32_t* rgba,
-                float4* linear, unsigned long long* segments, uint32_t* work, float4* fold, RtCamera cam, RtLaunch L) {
+                float4* linear, unsigned long long* segments, uint32_t* work, float4* fold, const float4* camterms,
+                RtCamera cam, RtLaunch L) {
     Scene sc = {geom, exact, shade, mat};
-    render_queue_body<false>(sc, rgba, linear, segments, work, fold, cam, L);
+    render_queue_body<false>(sc, rgba, linear, segments, work, fold, camterms, cam, L);
 }
 
 extern "C" __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(5)))
 rt_render_queue_stream(const float4* geom, const float4* exact, const float4* shade, const uint32_t* mat, uint32_t* rgba,
-                       float4* linear, unsigned long long* segments, uint32_t* work, float4* fold, RtCamera cam, RtLaunch L) {
+                       float4* linear, unsigned long long* segments, uint32_t* work, float4* fold, const float4* camterms,
+                       RtCamera cam, RtLaunch L) {
     Scene sc = {geom, exact, shade, mat};
-    render_queue_stream_body<false>(sc, rgba, linear, segments, work, fold, cam, L);
+    render_queue_stream_body<false>(sc, rgba, linear, segments, work, fold, camterms, cam, L);
 }
 
 // The same two kernels in fold-order mode (RtParams.sample_chunk = 0): finished samples are parked in the
@@ -1324,23 +1330,74 @@ rt_render_queue_stream(const float4* geom, const float4* exact, const float4* sh
 // summation order (ray.cu:123-129, lib.rs:228-231) at the speed of the exact-accumulation kernels.
 extern "C" __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(5)))
 rt_render_queue_fold(const float4* geom, const float4* exact, const float4* shade, const uint32_t* mat, uint32_t* rgba,
-                     float4* linear, unsigned long long* segments, uint32_t* work, float4* fold, RtCamera cam, RtLaunch L) {
+                     float4* linear, unsigned long long* segments, uint32_t* work, float4* fold, const float4* camterms,
+                     RtCamera cam, RtLaunch L) {
     Scene sc = {geom, exact, shade, mat};
-    render_queue_body<true>(sc, rgba, linear, segments, work, fold, cam, L);
+    render_queue_body<true>(sc, rgba, linear, segments, work, fold, camterms, cam, L);
 }
 
 extern "C" __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(5)))
 rt_render_queue_stream_fold(const float4* geom, const float4* exact, const float4* shade, const uint32_t* mat, uint32_t* rgba,
-                            float4* linear, unsigned long long* segments, uint32_t* work, float4* fold, RtCamera cam, RtLaunch L) {
+                            float4* linear, unsigned long long* segments, uint32_t* work, float4* fold, const float4* camterms,
+                            RtCamera cam, RtLaunch L) {
     Scene sc = {geom, exact, shade, mat};
-    render_queue_stream_body<true>(sc, rgba, linear, segments, work, fold, cam, L);
+    render_queue_stream_body<true>(sc, rgba, linear, segments, work, fold, camterms, cam, L);
 }
 
 extern "C" __global__ void __launch_bounds__(1024)
 rt_render_stream(const float4* geom, const float4* exact, const float4* shade, const uint32_t* mat, uint32_t* rgba,
-                 float4* linear, unsigned long long* segments, uint32_t* work, float4* fold, RtCamera cam, RtLaunch L) {
+                 float4* linear, unsigned long long* segments, uint32_t* work, float4* fold, const float4* camterms,
+                 RtCamera cam, RtLaunch L) {
     Scene sc = {geom, exact, shade, mat};
     render_body<true>(sc, rgba, linear, segments, work, cam, L);
+}
+
+// ---------------------------------------------------------------- camera-ray terms
+// Per sphere, the four numbers of scan_primary for this launch's camera: {A, B, C, sq}.  One work-item per
+// (padded) sphere, double precision; run on the launch stream before the camera-ray-batch kernels.
+//   exact[i] = {c, r*r} (r*r = -inf for padding)
+extern "C" __global__ void __launch_bounds__(256)
+rt_camera_terms(const float4* __restrict__ exact, float4* __restrict__ camterms, RtCamera cam, RtLaunch L) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= L.n_padded) return;
+    const float4 s = exact[i];
+    const double o[3] = {cam.center[0], cam.center[1], cam.center[2]};
+    const double q[3] = {(double)s.x - o[0], (double)s.y - o[1], (double)s.z - o[2]};
+    const double du[3] = {cam.pixel_delta_u[0], cam.pixel_delta_u[1], cam.pixel_delta_u[2]};
+    const double dv[3] = {cam.pixel_delta_v[0], cam.pixel_delta_v[1], cam.pixel_delta_v[2]};
+    const double p0[3] = {(double)cam.pixel00_loc[0] - o[0], (double)cam.pixel00_loc[1] - o[1], (double)cam.pixel00_loc[2] - o[2]};
+    const double A = du[0] * q[0] + du[1] * q[1] + du[2] * q[2];
+    const double B = dv[0] * q[0] + dv[1] * q[1] + dv[2] * q[2];
+    const double C = p0[0] * q[0] + p0[1] * q[1] + p0[2] * q[2];
+    const double qq = q[0] * q[0] + q[1] * q[1] + q[2] * q[2];
+    const double W1 = (double)L.width + 1.0, H1 = (double)L.height + 1.0;   // |fx| <= W + 1, |fy| <= H + 1
+    // F: distance from the camera centre to the image plane (a lower bound of |d|)
+    const double n[3] = {du[1] * dv[2] - du[2] * dv[1], du[2] * dv[0] - du[0] * dv[2], du[0] * dv[1] - du[1] * dv[0]};
+    const double nn = sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+    const double F = fabs(p0[0] * n[0] + p0[1] * n[1] + p0[2] * n[2]) / nn;
+    // eta: how far make_ray's rounded direction can be from P0 + fx du + fy dv.  Per component k its four roundings
+    // (dv*fy, the fma, + pixel00, - o) are each below 2^-24 of a partial result, together
+    // 2^-24 (|pixel00_k| + |P0_k| + 3 W1 |du_k| + 4 H1 |dv_k|)
+    double eta = 0.0;
+    for (int k = 0; k < 3; k++) {
+        const double e = 0x1p-24 * (fabs((double)cam.pixel00_loc[k]) + fabs(p0[k]) + 3.0 * W1 * fabs(du[k]) + 4.0 * H1 * fabs(dv[k]));
+        eta += e * e;
+    }
+    eta = sqrt(eta);
+    const double M = fabs(C) + W1 * fabs(A) + H1 * fabs(B);
+    const double s_abs = (4.0 * 0x1p-24 * M + 2.0 * sqrt(qq) * eta) / F + 0x1p-22 * sqrt(qq);
+    const double ntm = qq * (1.0 - 0x1p-18) - (double)s.w * (1.0 + 0x1p-17);
+    float sq;
+    if (ntm > 0.0 && F > 0.0 && s_abs == s_abs && s_abs < HUGE_VAL) {
+        const double v = sqrt(ntm) * (1.0 - 0x1p-20) - s_abs;
+        sq = (float)v;
+        if ((double)sq > v || sq != sq) sq = __uint_as_float(__float_as_uint(sq) + (sq > 0.0f ? 0xffffffffu : 1u));   // round down
+        if (v <= 0.0) sq = -INFINITY;                           // nothing left of the bound: always a candidate
+    } else {
+        sq = -INFINITY;                                          // camera inside the (inflated) sphere, NaN, or no image plane
+    }
+    if (s.w == -INFINITY) sq = INFINITY;                         // padding: never a candidate
+    camterms[i] = make_float4((float)A, (float)B, (float)C, sq);
 }
 
 // ---------------------------------------------------------------- primary-hit index map
@@ -1352,7 +1409,8 @@ rt_primary_hits(const float4* geom, const float4* exact, int32_t* hits, RtCamera
     uint32_t x, ly, y;
     const bool valid = map_pixel(L, wave_tile, lane, x, ly, y);
     V3 o, d;
-    make_ray(cam, x, y, 0.0f, 0.0f, o, d);
+    float fx_unused, fy_unused;
+    make_ray(cam, x, y, 0.0f, 0.0f, o, d, fx_unused, fy_unused);
     const float a = vdot(d, d);
     Best b;
     b.t = L.t_max;

@@ -8,10 +8,12 @@ Kernel (rt_kernels.hip, scan_tile), with T the scene translation, c' = fl(c - T)
   key = fma(g, g, t) + m                               m = r*r(1+2^-17) - |c'|^2 (1-2^-18), rounded up;
   candidate iff sign(key) clear.
 Exact test (checker order):  disc = fma(h, h, a*ncc),  h = d.oc,  ncc = r*r - oc.oc, oc = c - o;  needs disc >= 0.
-Camera rays (scan_primary) share their origin, so t + m is formed once per sphere when the tile is staged,
-  tm = fl(t + m)   with t as above for the camera centre,      key = fma(g, g, tm):
-one rounding moves from the end of the chain to tm.  Every case below checks both forms (any origin can be a
-camera centre).
+Camera rays (scan_primary) share their origin o and their directions are affine in the image coordinates,
+d = P0 + fx du + fy dv, so with q = c - o the condition becomes |d.q| / |d| >= sqrt(|q|^2 - r*r) and d.q = C + fx A + fy B:
+  rt_camera_terms (double precision, once per launch and sphere): A = du.q, B = dv.q, C = P0.q,
+      sq = sqrt(|q|^2 (1-2^-18) - r*r (1+2^-17)) (1-2^-20) - s_abs, rounded down   (s_abs: see the kernel's comment)
+  scan:  dq = fma(fx, A, fma(fy, B, C));  key = fma(|dq|, rsq(d.d)(1+2^-19), -sq);  candidate iff sign(key) clear.
+The direction the exact test sees is make_ray's rounded one; the filter works from fx, fy.
 Here both are evaluated in numpy with float32 fma emulated through float64 (products of two float32 are
 exact in float64), on random and adversarial ray/sphere pairs."""
 import numpy as np
@@ -51,8 +53,7 @@ def filt(o, d, c, rr, a, T, rsq_ulp=0):
     k0 = -((dot(op, op) * f32(1.0 - 2.0 ** -18)).astype(f32))
     t = fma(w[2], cp[2], fma(w[1], cp[1], fma(w[0], cp[0], k0)))
     g = fma(uf[2], cp[2], fma(uf[1], cp[1], fma(uf[0], cp[0], e)))
-    tm = (t + m).astype(f32)                       # staged once per sphere for the camera centre (geo0.w)
-    return (fma(g, g, t) + m).astype(f32), fma(g, g, tm)
+    return (fma(g, g, t) + m).astype(f32)
 
 
 def check(o, d, c, r, label, T=(0.0, 0.0, 0.0)):
@@ -64,11 +65,10 @@ def check(o, d, c, r, label, T=(0.0, 0.0, 0.0)):
     accepted = disc >= 0
     assert accepted.sum() > 0, label
     for rsq_ulp in (-1, 0, 1):
-        q, q5 = filt(o, d, c, rr, a, [f32(x) for x in T], rsq_ulp)
-        for form, key in (("scan_tile", q), ("scan_primary", q5)):
-            dropped = accepted & np.signbit(key)
-            assert not dropped.any(), (f"{label}: {dropped.sum()} exact-test candidates dropped by the {form} filter "
-                                       f"(1/sqrt off by {rsq_ulp} ulp)")
+        key = filt(o, d, c, rr, a, [f32(x) for x in T], rsq_ulp)
+        dropped = accepted & np.signbit(key)
+        assert not dropped.any(), (f"{label}: {dropped.sum()} exact-test candidates dropped by the scan_tile filter "
+                                   f"(1/sqrt off by {rsq_ulp} ulp)")
     return accepted.mean()
 
 
@@ -141,17 +141,16 @@ def test_extreme_scales():
         check(list(o + 1000.0 * scale), list(d), list(c + 1000.0 * scale), r, f"scale {scale} dir {dscale}, far from T")
 
 
-def test_camera_inside_spheres_on_surfaces_and_far_from_the_translation():
-    """The cases where the one moved rounding of the camera-ray form could matter: the camera centre inside a
-    sphere (every ray hits), exactly on a surface, and a scene whose spheres lie 1e3 .. 1e5 from the translation T
-    (large |c'|: large cancelling terms in t + m)."""
+def test_origins_inside_spheres_on_surfaces_and_far_from_the_translation():
+    """Origins inside a sphere (every ray hits), exactly on a surface, and scenes whose spheres lie 1e3 .. 1e5 from the
+    translation T (large |c'|: large cancelling terms in the expansion)."""
     rng = np.random.default_rng(5)
     n = 1_000_000
     c = rng.uniform(-10, 10, (3, n)); r = rng.uniform(0.5, 30.0, n)
     o = c + unit(rng, n) * r * rng.uniform(0.0, 0.999, n)                   # inside
-    assert check(list(o), list(unit(rng, n) * rng.uniform(0.1, 4.0, n)), list(c), r, "camera inside") == 1.0
+    assert check(list(o), list(unit(rng, n) * rng.uniform(0.1, 4.0, n)), list(c), r, "origin inside") == 1.0
     o = c + unit(rng, n) * r                                                  # on the surface, to rounding
-    check(list(o), list(unit(rng, n)), list(c), r, "camera on a surface")
+    check(list(o), list(unit(rng, n)), list(c), r, "origin on a surface")
     for far in (1e3, 1e4, 1e5):
         c = rng.uniform(-20, 20, (3, n)) + far * unit(rng, 1)
         r = rng.uniform(0.05, 2.0, n)
@@ -161,3 +160,128 @@ def test_camera_inside_spheres_on_surfaces_and_far_from_the_translation():
         check(list(o), list(d), list(c), r, f"centres {far:g} from T")
         # and with T where the kernel would put it (the median of the centres): the same pairs, small |c'|
         check(list(o), list(d), list(c), r, f"centres {far:g} from the origin, T at their median", T=tuple(np.median(c, axis=1)))
+
+
+# ---------------------------------------------------------------- camera rays (scan_primary, rt_camera_terms)
+def _cam_arrays(cam):
+    b = cam.block
+    g = lambda v: np.array(list(v), dtype=f32)
+    return g(b.center), g(b.pixel00_loc), g(b.pixel_delta_u), g(b.pixel_delta_v), int(b.image_width), int(b.image_height)
+
+
+def camera_ray(cam, fx, fy):
+    """make_ray of the kernel: pc = pixel00 + fma(du, fx, dv * fy); d = pc - centre (single precision)."""
+    o, p00, du, dv, _, _ = _cam_arrays(cam)
+    d = []
+    for k in range(3):
+        off = fma(np.full_like(fx, du[k]), fx, (np.full_like(fy, dv[k]) * fy).astype(f32))
+        pc = (p00[k] + off).astype(f32)
+        d.append((pc - o[k]).astype(f32))
+    return [np.full_like(fx, o[k]) for k in range(3)], d
+
+
+def camera_terms(cam, c, rr):
+    """rt_camera_terms, operation for operation, in double precision; results rounded as the kernel rounds them."""
+    o, p00, du, dv, W, H = [x.astype(np.float64) if isinstance(x, np.ndarray) else x for x in _cam_arrays(cam)]
+    q = [c[k].astype(np.float64) - o[k] for k in range(3)]
+    p0 = p00 - o
+    A = sum(du[k] * q[k] for k in range(3))
+    B = sum(dv[k] * q[k] for k in range(3))
+    C = sum(p0[k] * q[k] for k in range(3))
+    qq = sum(q[k] * q[k] for k in range(3))
+    W1, H1 = W + 1.0, H + 1.0
+    nrm = np.cross(du, dv)
+    F = abs(np.dot(p0, nrm)) / np.linalg.norm(nrm)
+    eta = np.sqrt(sum((2.0 ** -24 * (abs(p00[k]) + abs(p0[k]) + 3.0 * W1 * abs(du[k]) + 4.0 * H1 * abs(dv[k]))) ** 2 for k in range(3)))
+    M = np.abs(C) + W1 * np.abs(A) + H1 * np.abs(B)
+    s_abs = (4.0 * 2.0 ** -24 * M + 2.0 * np.sqrt(qq) * eta) / F + 2.0 ** -22 * np.sqrt(qq)
+    ntm = qq * (1.0 - 2.0 ** -18) - rr.astype(np.float64) * (1.0 + 2.0 ** -17)
+    with np.errstate(invalid="ignore"):
+        v = np.sqrt(np.maximum(ntm, 0.0)) * (1.0 - 2.0 ** -20) - s_abs
+    sq = v.astype(f32)
+    sq = np.where(sq.astype(np.float64) > v, np.nextafter(sq, f32(-np.inf)), sq)
+    sq = np.where((ntm > 0.0) & (v > 0.0), sq, f32(-np.inf)).astype(f32)
+    return A.astype(f32), B.astype(f32), C.astype(f32), sq
+
+
+def check_camera(cam, fx, fy, c, r, label):
+    fx, fy = fx.astype(f32), fy.astype(f32)
+    c = [x.astype(f32) for x in c]
+    rr = (r.astype(f32) * r.astype(f32)).astype(f32)
+    o, d = camera_ray(cam, fx, fy)
+    _, a, _, _, disc = terms(o, d, c, rr)
+    A, B, C, sq = camera_terms(cam, c, rr)
+    accepted = disc >= 0
+    assert accepted.sum() > 0, label
+    dq = fma(fx, A, fma(fy, B, C))
+    for rsq_ulp in (-1, 0, 1):
+        rsq = (1.0 / np.sqrt(a.astype(np.float64))).astype(f32)
+        if rsq_ulp:
+            rsq = np.nextafter(rsq, f32(np.inf) if rsq_ulp > 0 else f32(0.0))
+        ils = (rsq * f32(1.0 + 2.0 ** -19)).astype(f32)
+        with np.errstate(invalid="ignore"):
+            key = fma(np.abs(dq), ils, -sq)
+        dropped = accepted & np.signbit(key)
+        assert not dropped.any(), f"{label}: {dropped.sum()} exact-test candidates dropped by the camera-ray filter (1/sqrt off by {rsq_ulp} ulp)"
+    return accepted, ~np.signbit(key)
+
+
+def _cameras():
+    import ray_tracing_amd as rt
+    return {
+        "book 4K": rt.Camera.look_at(16 / 9, 3840, 20.0, (13, 2, 3), (0, 0, 0)),
+        "hall 8K": rt.Camera.look_at(16 / 9, 7680, 90.0, (0, 0, -85), (0, 0, -70)),
+        "grid": rt.Camera.look_at(16 / 9, 1920, 40.0, (0, 30, 80), (0, 0, 0)),
+        "cpu crate 1920": rt.Camera.new_cpu(16 / 9, 1920),
+        "cpu crate 256": rt.Camera.new_cpu(16 / 9, 256),
+        "far from the origin": rt.Camera.look_at(16 / 9, 1280, 35.0, (10013, 2002, -4997), (10000, 2000, -5000)),
+        "very far from the origin": rt.Camera.look_at(4 / 3, 640, 60.0, (3.0e5, -1.0e5, 2.0e5), (3.0e5 + 3, -1.0e5, 2.0e5 + 4)),
+        "narrow": rt.Camera.look_at(1.0, 512, 0.5, (0, 0, 50), (0, 0, 0)),
+    }
+
+
+def test_camera_ray_filter_grazing_and_random():
+    """Rays through random image points (pixel + jitter) against spheres placed so that the ray grazes them within a
+    few ulps, passes well inside, or misses; cameras of every benchmark configuration and some hostile ones."""
+    rng = np.random.default_rng(6)
+    n = 400_000
+    for name, cam in _cameras().items():
+        o_, p00, du, dv, W, H = _cam_arrays(cam)
+        fx = rng.integers(0, W, n) + rng.uniform(-0.5, 1.0, n)
+        fy = rng.integers(0, H, n) + rng.uniform(-0.5, 1.0, n)
+        _, d = camera_ray(cam, fx.astype(f32), fy.astype(f32))
+        d64 = np.stack([x.astype(np.float64) for x in d])
+        dl = np.linalg.norm(d64, axis=0)
+        u = d64 / dl
+        perp = np.cross(u.T, unit(rng, n).T).T
+        perp /= np.linalg.norm(perp, axis=0)
+        scale = max(1.0, float(np.linalg.norm(p00.astype(np.float64) - o_.astype(np.float64))))
+        r = rng.uniform(0.05, 2.0, n) * rng.choice([1.0, 1.0, 30.0], n)
+        dist = rng.uniform(0.2, 80.0, n) * scale * rng.choice([1.0, -1.0], n, p=[0.9, 0.1])   # some centres behind the camera
+        for kind, miss in (("grazing", 1.0 + rng.uniform(-4e-7, 4e-7, n)), ("random", rng.uniform(0.0, 1.5, n))):
+            c = o_.astype(np.float64)[:, None] + u * dist + perp * r * miss
+            acc, cand = check_camera(cam, fx, fy, list(c), r, f"{name}, {kind}")
+            assert acc.mean() > 0.05, (name, kind, acc.mean())
+            if kind == "random" and "far" not in name:
+                # the filter stays tight where scenes live (spheres within a few focal lengths, at least half a degree across): few listed in vain
+                near = (np.abs(dist) < 3.0 * scale) & (r > 0.01 * np.abs(dist))
+                assert cand[near].mean() < acc[near].mean() + 0.05, (name, cand[near].mean(), acc[near].mean())
+
+
+def test_camera_ray_filter_camera_inside_on_surfaces_and_the_ground_sphere():
+    rng = np.random.default_rng(7)
+    n = 300_000
+    for name, cam in _cameras().items():
+        o_, p00, du, dv, W, H = _cam_arrays(cam)
+        o64 = o_.astype(np.float64)[:, None]
+        fx = rng.integers(0, W, n) + rng.uniform(-0.5, 1.0, n)
+        fy = rng.integers(0, H, n) + rng.uniform(-0.5, 1.0, n)
+        r = rng.uniform(0.5, 30.0, n)
+        c = o64 + unit(rng, n) * r * rng.uniform(0.0, 0.999, n)                         # camera inside: every ray hits
+        assert check_camera(cam, fx, fy, list(c), r, f"{name}, camera inside")[0].mean() > (0.5 if "far" in name else 0.999)
+        c = o64 + unit(rng, n) * r                                                        # camera on the surface, to rounding
+        check_camera(cam, fx, fy, list(c), r, f"{name}, camera on a surface")
+        # a huge sphere just below the camera (the book scene's ground), rays near its horizon included
+        r = np.full(n, 1000.0)
+        c = o64 + np.stack([rng.uniform(-5, 5, n), -1000.0 - rng.uniform(1e-4, 3.0, n), rng.uniform(-5, 5, n)])
+        check_camera(cam, fx, fy, list(c), r, f"{name}, ground sphere")
