@@ -266,7 +266,8 @@ int launch_render(rt_ctx* c, const RtCamera* cam, const RtParams* p, RtLaunch L,
                   uint64_t* rays_out, void* counters, bool fold_workspace = true) {
     unsigned grid, block;
     launch_geometry(p, L.n_units, &grid, &block);
-    const unsigned waves = block / 64u, P = L.unit_w * L.unit_h;
+    unsigned waves = block / 64u;
+    const unsigned P = L.unit_w * L.unit_h;
     hipFunction_t f;
     unsigned lds;
     if ((uint64_t)P * L.n_chunks >= (1ull << 31)) return fail(c, RT_ERR_INVALID, "too many work items per pixel unit (samples_per_pixel / sample_chunk too large)");
@@ -281,6 +282,13 @@ int launch_render(rt_ctx* c, const RtCamera* cam, const RtParams* p, RtLaunch L,
         } else {
             f = one_tile ? c->f_render_queue : c->f_render_queue_stream;
             c->last_kernel = one_tile ? "rt_render_queue" : "rt_render_queue_stream";
+        }
+        if (one_tile && !L.fold && p->block_dim == 0u) {
+            // rt_render_queue is built for six waves per SIMD; with 512-thread workgroups three of them (24 wavefronts)
+            // fit a compute unit's LDS on the 485-sphere scene, with 256 threads only five (20 wavefronts)
+            block = 512u;
+            waves = block / 64u;
+            grid = (L.n_units + waves - 1u) / waves;
         }
         lds = (one_tile ? c->n_padded : RT_Q_STREAM_TILE) * 32u + waves * (RT_Q_CAND_CAP * 128u + 48u * P + RT_Q_WORDS * 256u);
     } else {
