@@ -101,7 +101,9 @@ def code_object_sha256():
     return hashlib.sha256(open(path, "rb").read()).hexdigest() if os.path.exists(path) else None
 
 
-def stamped_traffic():
+def stamped_traffic(workload):
+    """HBM bytes per launch from a PMC profile kept under profiles/ -- only one taken with the code object this run
+    executes (SHA-256 stamp) AND on this workload (the profile records bench.py's own workload string)."""
     import glob
     sha = code_object_sha256()
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")), reverse=True):
@@ -109,7 +111,7 @@ def stamped_traffic():
             rec = json.load(open(f))
         except Exception:
             continue
-        if sha and rec.get("code_object_sha256") == sha:
+        if sha and rec.get("code_object_sha256") == sha and rec.get("workload") == workload:
             return rec.get("hbm_bytes_per_launch")
     return None
 
@@ -213,9 +215,10 @@ def main():
         achieved = rank0_rays_per_launch * flop_per_segment / (k_ms * 1e-3) * 1e-12 if k_ms > 0 else 0.0
         # HBM bytes per launch from the PMC passes kept under profiles/ -- only if they were taken with the code
         # object this run executes (the file is stamped with its SHA-256) and on this workload; else null
-        traffic = None
-        if world == 1 and (args.workload, args.width, args.spp, args.depth, args.sample_chunk) == ("c3", 3840, 500, 50, 1):
-            traffic = stamped_traffic()
+        workload_text = (f"{args.workload}: {WORKLOADS[args.workload][0]}, {n_sph} spheres, {W}x{H}, {args.spp} spp, max depth {args.depth}, "
+                         f"jittered sampler, seed 1, sample_chunk {args.sample_chunk}; frame split into interleaved {TILE_ROWS}-row tiles over "
+                         f"{world} GPU(s), RCCL gather to rank 0")
+        traffic = stamped_traffic(workload_text) if world == 1 else None
         out = {
             "metric": "Mrays/s (primary+bounce) at 1/2/4/8 MI355X + % of FP32 VALU peak",
             "value": rays_all / elapsed_max * 1e-6,
@@ -229,9 +232,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {WORKLOADS[args.workload][0]}, {n_sph} spheres, {W}x{H}, {args.spp} spp, max depth {args.depth}, "
-                                   f"jittered sampler, seed 1, sample_chunk {args.sample_chunk}; frame split into interleaved {TILE_ROWS}-row tiles over "
-                                   f"{world} GPU(s), RCCL gather to rank 0",
+            "config": {"workload": workload_text,
                        "spheres": n_sph, "width": W, "height": H, "spp": args.spp, "max_depth": args.depth, "sample_chunk": args.sample_chunk,
                        "segments_per_frame": rays_all / max(1, args.steps), "parallelism": f"rowtiles{world}"},
             "roofline": {"bound": "valu_fp32", "achieved": achieved, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",

@@ -59,8 +59,10 @@ if os.path.exists(asm):
     m = re.search(r"\.name:\s+" + re.escape(KERNEL) + r"\n(?:.*\n)*?\s+\.vgpr_count:\s+(\d+)", text)
     vgprs = int(m.group(1)) if m else None
 w(f"  launched: Grid_Size / 64 = {waves} wavefronts.  rocprofv3's VGPR_Count is half of what the compiler reports for the same kernel")
-w(f"  (code object metadata: {KERNEL} .vgpr_count {vgprs}, allocated in granules of 8 -> {((vgprs + 7) // 8 * 8) if vgprs else '?'}, within the 96 that 5 waves per SIMD")
-w("  of a 512-register file allow and that the measured residency below confirms; the dispatch row divides the descriptor's")
+alloc = ((vgprs + 7) // 8 * 8) if vgprs else None
+w(f"  (code object metadata: {KERNEL} .vgpr_count {vgprs}, allocated in granules of 8 -> {alloc if alloc else '?'}: "
+  f"{(512 // alloc) if alloc else '?'} waves per SIMD of a 512-register file,")
+w("  which the measured residency below confirms; the dispatch row divides the descriptor's")
 w("  8-register granules by two).")
 if pmc.get("SQ_WAVES") and waves:
     w(f"  SQ_WAVES reads {pmc['SQ_WAVES']:.0f} = {pmc['SQ_WAVES'] / waves:.2f} x the wavefronts launched.")
@@ -72,7 +74,7 @@ w("")
 w("derived:")
 if pmc.get("SQ_INSTS_VALU"):
     w(f"  ray segments per launch            {seg:.0f}")
-    w(f"  VALU wave-instructions per segment {pmc['SQ_INSTS_VALU'] / seg * 64:.1f} x 64 (scan alone: {n_pad} x 9 = {n_pad * 9} per bounce segment, {n_pad} x 5 per camera ray)")
+    w(f"  VALU wave-instructions per segment {pmc['SQ_INSTS_VALU'] / seg * 64:.1f} x 64 (scan alone: {n_pad} x 9 = {n_pad * 9} per bounce segment, {n_pad} x 4 per camera ray)")
     w(f"  active lanes per VALU instruction  {pmc['SQ_THREAD_CYCLES_VALU'] / pmc['SQ_INSTS_VALU']:.1f} of 64 ({100 * pmc['SQ_THREAD_CYCLES_VALU'] / pmc['SQ_INSTS_VALU'] / 64:.1f} %)  <- branch divergence")
     w(f"  LDS instructions per VALU instr    {pmc['SQ_INSTS_LDS'] / pmc['SQ_INSTS_VALU']:.3f}")
     w(f"  SALU instructions per VALU instr   {pmc['SQ_INSTS_SALU'] / pmc['SQ_INSTS_VALU']:.3f}")
