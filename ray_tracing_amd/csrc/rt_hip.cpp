@@ -218,17 +218,29 @@ RtLaunch make_launch(const rt_ctx* c, const RtCamera* cam, const RtParams* p, ui
         L.fold = fold ? 1u : 0u;                                        // samples traced in any order, added in sample order
         L.chunk = fold ? 1u : p->sample_chunk;
         L.n_chunks = (spp + L.chunk - 1u) / L.chunk;
-        // Unit shape only affects scheduling (the sums are exact).  A wavefront has two units open at a time, so
-        // small units cost nothing inside the wavefront, and they shorten the end of the launch, when the last
-        // units are still running and the other wavefronts have nothing left to take.  Measured on the book
-        // scene at 4K, 500 spp: 4x1, 8x1, 16x1 and 2x2 all run the full frame in 1122-1130 ms; an eighth of the
-        // frame (the share of one of 8 GPUs) takes 146, 151, 166 and 144 ms.  4x1 rather than 2x2: a unit is
-        // written as one 16-byte row segment (2x2: two 8-byte ones, 5x the frame's bytes in HBM writes).
-        // A unit must lie in one row tile: any height does when the rows are contiguous.
+        // Unit shape only affects scheduling (the sums are exact).  4x1 rather than 2x2: a unit is written as one
+        // 16-byte row segment (2x2: two 8-byte ones, 5x the frame's bytes in HBM writes).  A unit must lie in one row
+        // tile: any height does when the rows are contiguous.
         auto height_ok = [&](uint32_t h) { return tile_stride_rows == tile_rows || tile_rows % h == 0u; };
         L.unit_w = 4u; L.unit_h = 1u;
-        while (L.unit_w * L.unit_h < 64u && (uint64_t)L.unit_w * L.unit_h * L.n_chunks < 64u * 8u) {   // too few items per lane
-            if (L.unit_h < L.unit_w && height_ok(2u * L.unit_h)) L.unit_h *= 2u; else L.unit_w *= 2u;
+        // A wavefront holds two units at a time and cannot open a third before the older one's last, longest paths have
+        // ended, so a unit must be enough work to outlast them: measured on the camera-ray-batch kernels, units of 2,000 to
+        // 4,000 samples run at full speed, 512 samples 20 % below it (book scene, 128 spp, 4x1 against 16x1 units).  Units
+        // grow (wider first: one row segment per unit is written) until they hold 2,048 samples -- but only while the
+        // launch still has 80 units per resident wavefront (24 per compute unit): the end of the launch, when nothing is
+        // left to take, lasts about two units (4K book frame at 500 spp: the whole frame runs 1 % faster with 8x1 units,
+        // 169 per wavefront, a quarter of it 3 % slower with 42 per wavefront than with 4x1 and 84).
+        // Below 512 samples a unit grows regardless: it has to fill its camera-ray batches.
+        const uint64_t resident = (uint64_t)(c->compute_units > 0 ? c->compute_units : 256) * 24u;
+        auto n_units_with = [&](uint32_t w, uint32_t h) {
+            return (uint64_t)((cam->image_width + w - 1u) / w) * ((rows_local + h - 1u) / h);
+        };
+        while (L.unit_w * L.unit_h < 64u) {
+            const uint64_t items = (uint64_t)L.unit_w * L.unit_h * L.n_chunks, samples = (uint64_t)L.unit_w * L.unit_h * spp;
+            uint32_t w = L.unit_w, h = L.unit_h;
+            if (w < 16u || !height_ok(2u * h)) w *= 2u; else h *= 2u;
+            if (items >= 512u && (samples >= 2048u || n_units_with(w, h) < 80u * resident)) break;
+            L.unit_w = w; L.unit_h = h;
         }
         if (c->dbg_unit_w && height_ok(c->dbg_unit_h)) { L.unit_w = c->dbg_unit_w; L.unit_h = c->dbg_unit_h; }   // rt_debug_schedule
         // fold-order workspace: 2 units x P pixels x spp colours of 16 bytes per wavefront, at most 32 wavefronts per
