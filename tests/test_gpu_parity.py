@@ -277,6 +277,44 @@ def test_camera_ray_batches_edge_cases(oracle, rt, hip):
         hip.debug_schedule(unit=(3, 1))
 
 
+def test_camera_ray_scan_with_hostile_cameras(oracle, rt, hip):
+    """The camera-ray scan works from per-sphere terms computed for the launch's camera (rt_camera_terms): cameras
+    inside a glass sphere, on a sphere's surface, just above the huge ground sphere, far from the origin (the whole
+    scene moved by 1e4), with a very narrow and a very wide field of view -- every sample its own item
+    (rt_render_queue) and the streamed kernel, bit for bit against the checker."""
+    rng = np.random.default_rng(77)
+
+    def scene(n, shift=(0.0, 0.0, 0.0)):
+        sp = np.zeros(n, rt.SPHERE_DTYPE)
+        sp["center"] = (rng.uniform(-5, 5, (n, 3)) + np.array(shift)).astype(np.float32)
+        sp["radius"] = np.exp(rng.uniform(np.log(0.1), np.log(1.5), n)).astype(np.float32)
+        sp["center"][0] = np.array(shift, np.float32) + np.float32([0.0, -1000.0, 0.0]); sp["radius"][0] = 1000.0
+        sp["center"][1] = np.array(shift, np.float32) + np.float32([0.0, 1.0, 0.0]); sp["radius"][1] = 1.0
+        sp["material"] = rng.choice([1, 2, 3], n, p=[0.5, 0.3, 0.2]); sp["material"][1] = 3
+        sp["albedo"] = rng.uniform(0.2, 1.0, (n, 3)).astype(np.float32)
+        sp["param"] = np.where(sp["material"] == 3, 1.5, rng.uniform(0.0, 1.0, n)).astype(np.float32)
+        return sp
+
+    p = rt.DeviceGUI(samples_per_pixel=6, max_depth=12, seed=3, sample_chunk=1)
+    cases = [
+        ("inside the glass sphere", scene(40), (0.1, 1.2, -0.2), (3.0, 0.5, 1.0), 60.0),
+        ("on the glass sphere's surface", scene(40), (0.0, 2.0, 0.0), (2.0, 0.0, 2.0), 70.0),
+        ("just above the ground", scene(40), (4.0, 1e-3, 4.0), (0.0, 0.5, 0.0), 50.0),
+        ("narrow", scene(40), (20.0, 3.0, 15.0), (0.0, 1.0, 0.0), 1.5),
+        ("wide", scene(40), (2.0, 2.0, 2.0), (0.0, 0.5, 0.0), 150.0),
+        ("far from the origin", scene(40, (1.0e4, -2.0e3, 5.0e3)), (1.0e4 + 9.0, -2.0e3 + 2.0, 5.0e3 + 6.0),
+         (1.0e4, -2.0e3 + 0.5, 5.0e3), 40.0),
+        ("streamed list", scene(1100), (9.0, 3.0, 7.0), (0.0, 0.5, 0.0), 45.0),
+    ]
+    for name, sp, lookfrom, lookat, vfov in cases:
+        cam = rt.Camera.look_at(16.0 / 9.0, 96, vfov, lookfrom, lookat)
+        got, _ = check_render(oracle, hip, cam, sp, p)
+        assert hip.last_kernel_name() == ("rt_render_queue_stream" if len(sp) > 1024 else "rt_render_queue"), name
+        hits = hip.primary_hits(cam, p)
+        ref = oracle.primary_hits(oracle.camera_f32_from_rt(cam.block), sp, p.t_min, p.t_max, p.flags)
+        assert np.array_equal(hits, ref), name
+
+
 def test_randomised_scenes_all_modes(oracle, rt, hip):
     """Seeded random scenes (overlapping spheres, tiny and huge radii, all three materials, cameras inside and
     outside the cloud), random frame sizes, samplers, depths, block sizes and accumulation modes
