@@ -148,10 +148,16 @@ int rt_debug_counters(rt_ctx *ctx, uint64_t out[16]);
 
 /* Diagnostic: scheduling experiments on this context.  unit_w x unit_h (powers of two, at most 64 pixels;
  * 0, 0 = the library's choice) forces the shape of the pixel units the wavefronts take when sample_chunk > 0;
- * no_queue != 0 keeps sample_chunk = 1 on the work-item kernel instead of the camera-ray-batch kernel.  Neither
+ * no_queue != 0 keeps sample_chunk = 1 on the work-item kernel instead of the camera-ray-batch kernels;
+ * scheduler picks, for sample_chunk = 1 on sphere lists that fit one LDS tile, who holds the open pixel units:
+ * RT_SCHED_WAVE each wavefront two of its own (rt_render_queue), RT_SCHED_POOL the workgroup a pool shared by its
+ * wavefronts (rt_render_pool), RT_SCHED_AUTO the library's choice by the size of the launch.  None of these
  * changes a single bit of the image (exact accumulation), only the timing.  No counterpart in the reference
  * beyond its block_dim slider (gui.rs:287). */
-int rt_debug_schedule(rt_ctx *ctx, uint32_t unit_w, uint32_t unit_h, int no_queue);
+#define RT_SCHED_AUTO 0
+#define RT_SCHED_WAVE 1
+#define RT_SCHED_POOL 2
+int rt_debug_schedule(rt_ctx *ctx, uint32_t unit_w, uint32_t unit_h, int no_queue, int scheduler);
 
 /* Name and compute-unit count of the context's GPU. */
 int rt_device_info(const rt_ctx *ctx, char *name, size_t name_size, int *compute_units, int *clock_khz);

@@ -301,11 +301,14 @@ class HipWorld:
         self._check(self._lib.rt_debug_counters(self._ctx, C.byref(out)))
         return list(out)
 
-    def debug_schedule(self, unit=None, no_queue=False):
+    def debug_schedule(self, unit=None, no_queue=False, scheduler="auto"):
         """Scheduling experiments: unit = (w, h) forces the pixel-unit shape (None: the library's choice);
-        no_queue keeps sample_chunk = 1 on the work-item kernel.  The image does not change."""
+        no_queue keeps sample_chunk = 1 on the work-item kernel; scheduler = "wave" | "pool" | "auto" picks who holds
+        the open pixel units on the camera-ray-batch kernel (each wavefront its own, or a pool per workgroup).
+        The image does not change."""
         w, h = unit if unit else (0, 0)
-        self._check(self._lib.rt_debug_schedule(self._ctx, w, h, int(bool(no_queue))))
+        self._check(self._lib.rt_debug_schedule(self._ctx, w, h, int(bool(no_queue)),
+                                                {"auto": 0, "wave": 1, "pool": 2}[scheduler]))
 
     def device_info(self):
         name = C.create_string_buffer(600)

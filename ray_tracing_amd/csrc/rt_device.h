@@ -34,6 +34,7 @@ typedef struct RtLaunch {
     uint32_t n_chunks;         // ceil(samples_per_pixel / chunk); 1 = the reference's fp32 fold
     float    translate[3];     // T of the scan filter: component-wise median of the sphere centres
     uint32_t fold;             // queue kernels: 1 = finished samples go to the workspace and are added in sample order (fp32 fold)
+    uint32_t pool_slots;       // rt_render_pool: open units per workgroup (LDS pool)
 } RtLaunch;
 
 // Launch-wide counter block of the render kernels, device memory, cleared before every launch: sixteen 64-bit

@@ -39,7 +39,7 @@ struct rt_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipModule_t module = nullptr;
-    hipFunction_t f_render = nullptr, f_render_queue = nullptr, f_render_queue_fold = nullptr, f_render_queue_stream_fold = nullptr, f_render_stream = nullptr, f_render_queue_stream = nullptr, f_hits = nullptr, f_random = nullptr, f_assemble = nullptr, f_camera_terms = nullptr;
+    hipFunction_t f_render = nullptr, f_render_queue = nullptr, f_render_queue_fold = nullptr, f_render_queue_stream_fold = nullptr, f_render_stream = nullptr, f_render_queue_stream = nullptr, f_hits = nullptr, f_random = nullptr, f_assemble = nullptr, f_camera_terms = nullptr, f_render_pool = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     void *d_geom = nullptr, *d_exact = nullptr, *d_shade = nullptr, *d_mat = nullptr;
     void* d_camterms = nullptr;         // per sphere {A, B, C, sq} of the camera-ray scan, rewritten by every launch (rt_camera_terms)
@@ -53,6 +53,7 @@ struct rt_ctx {
     // scheduling experiments (rt_debug_schedule): forced unit shape (0 = the library's choice), item kernel for sample_chunk 1
     uint32_t dbg_unit_w = 0, dbg_unit_h = 0;
     bool dbg_no_queue = false;
+    int dbg_scheduler = 0;                                       // RT_SCHED_*: 0 = the library's choice between the two
     size_t cap_rgba = 0, cap_linear = 0, cap_hits = 0;
     void* d_fold = nullptr;             // fold-order workspace of the queue kernels: finished samples until their unit is complete
     size_t cap_fold = 0;
@@ -152,6 +153,7 @@ int load_image(rt_ctx* c, const void* image) {
     c->counter_need = need;
     if (c->module) (void)hipModuleUnload(c->module);
     c->module = m;
+    if (hipModuleGetFunction(&c->f_render_pool, m, "rt_render_pool") != hipSuccess) { c->f_render_pool = nullptr; (void)hipGetLastError(); }
     c->f_render_queue_fold = fqf; c->f_render_queue_stream_fold = fqsf; c->f_render = fr; c->f_render_queue = fq; c->f_render_queue_stream = fqs; c->f_render_stream = fs; c->f_hits = fh; c->f_random = fx; c->f_assemble = fa; c->f_camera_terms = fct;
     return 0;
 }
@@ -303,6 +305,26 @@ int launch_render(rt_ctx* c, const RtCamera* cam, const RtParams* p, RtLaunch L,
             grid = (L.n_units + waves - 1u) / waves;
         }
         lds = (one_tile ? c->n_padded : RT_Q_STREAM_TILE) * 32u + waves * (RT_Q_CAND_CAP * 128u + 48u * P + RT_Q_WORDS * 256u);
+        // Who holds the open pixel units: each wavefront two of its own (rt_render_queue), or the workgroup a pool of
+        // them from which all its wavefronts take camera rays (rt_render_pool).  The pool costs more bookkeeping per
+        // batch (4K book scene, 500 spp: 1.2 % slower; 8K mirror hall: 8 %), but no wavefront waits for its own units'
+        // last paths and the launch's last units are finished by whole workgroups: measured on the book scene it wins
+        // from a quarter of the 4K frame down (1/8: 2 %, 1/16: 18 %; 1080p at 128 spp: 7 %), on the mirror hall at
+        // 1080p (21 units per resident wavefront) but not at 4K (84).  Hence: the pool below 64 units per resident
+        // wavefront (24 per compute unit).
+        bool pool = one_tile && !L.fold && L.max_depth > 0u && c->f_render_pool != nullptr &&
+                    (uint64_t)L.n_units < 64ull * 24u * (uint64_t)(c->compute_units > 0 ? c->compute_units : 256);
+        if (c->dbg_scheduler == RT_SCHED_WAVE) pool = false;
+        if (c->dbg_scheduler == RT_SCHED_POOL) pool = one_tile && !L.fold && L.max_depth > 0u && c->f_render_pool != nullptr;
+        if (pool) {
+            f = c->f_render_pool;
+            c->last_kernel = "rt_render_pool";
+            // as many open units as the wavefronts would hold between them, so the same LDS: slot headers, the
+            // control words, the slots' accumulators, and per wavefront the candidate lists and the ray queue
+            L.pool_slots = 2u * waves;
+            lds = c->n_padded * 32u + L.pool_slots * 32u + 16u + L.pool_slots * 24u * P + waves * (RT_Q_CAND_CAP * 128u + RT_Q_WORDS * 256u);
+            grid = L.n_units;                                    // a unit is work for a whole workgroup
+        }
     } else {
         f = (c->n_padded <= RT_TILE_SPHERES) ? c->f_render : c->f_render_stream;
         c->last_kernel = (c->n_padded <= RT_TILE_SPHERES) ? "rt_render" : "rt_render_stream";
@@ -827,7 +849,7 @@ int rt_render_frame_sharded(rt_ctx* c, const RtCamera* cam, const RtParams* p, u
     return 0;
 }
 
-int rt_debug_schedule(rt_ctx* c, uint32_t unit_w, uint32_t unit_h, int no_queue) {
+int rt_debug_schedule(rt_ctx* c, uint32_t unit_w, uint32_t unit_h, int no_queue, int scheduler) {
     if (!c) return RT_ERR_INVALID;
     auto pow2 = [](uint32_t v) { return v && !(v & (v - 1u)); };
     if (unit_w || unit_h) {
@@ -836,7 +858,10 @@ int rt_debug_schedule(rt_ctx* c, uint32_t unit_w, uint32_t unit_h, int no_queue)
     }
     c->dbg_unit_w = unit_w;
     c->dbg_unit_h = unit_h;
+    if (scheduler != RT_SCHED_AUTO && scheduler != RT_SCHED_WAVE && scheduler != RT_SCHED_POOL)
+        return fail(c, RT_ERR_INVALID, "rt_debug_schedule: scheduler must be RT_SCHED_AUTO, RT_SCHED_WAVE or RT_SCHED_POOL");
     c->dbg_no_queue = no_queue != 0;
+    c->dbg_scheduler = scheduler;
     return 0;
 }
 

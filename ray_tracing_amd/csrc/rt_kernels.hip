@@ -970,7 +970,7 @@ RT_DEV void primary_batch(const Scene& sc, const Tile& tile, const float4* __res
         sphere = (uint32_t)b.idx;
         V3 color;
         if (shade_segment(sc, L, seed, b, pixel, s, band, p, color, st)) {
-            add_sample(acc, P, 3u * pix + (slot ? 3u * P : 0u), s, L.samples_per_pixel, color, fold);
+            add_sample(acc, P, 3u * pix + slot * 3u * P, s, L.samples_per_pixel, color, fold);
             done = true;
         } else {
             cont = true;
@@ -1106,6 +1106,313 @@ RT_DEV void render_queue_body(const Scene& sc, uint32_t* __restrict__ rgba, floa
             const uint32_t n1 = (uint32_t)__popcll(__ballot(finished && pixslot >= 3u * P));
             u1.left -= n1;
             u0.left -= (uint32_t)__popcll(fin) - n1;
+        }
+    }
+
+    if (segments) {
+        unsigned long long n64 = nseg;
+        for (int off = 32; off > 0; off >>= 1) n64 += __shfl_xor(n64, off);
+        if (lane == 0u && n64) atomicAdd(segments, n64);
+#ifdef RT_STATS
+        for (int w = 1; w < 8; w++) {
+            unsigned long long x = st.v[w];
+            for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
+            if (lane == 0u && x) atomicAdd(segments + w, x);
+        }
+        for (int w = 0; w < 7; w++)
+            if (lane == 0u) atomicAdd(segments + 9 + w, st.cyc[w]);
+#endif
+    }
+}
+
+// ---------------------------------------------------------------- render, units shared by the workgroup
+// The same path tracing as render_queue_body (exact accumulation), with the pixel units held by the WORKGROUP instead
+// of by each wavefront: a pool of L.pool_slots open units in LDS, from whose current unit every wavefront of the
+// workgroup takes its camera-ray batches (one LDS atomic per batch).  What this buys: (1) a unit's last, longest paths
+// hold up one pool slot, not the wavefront that traced them -- a wavefront never waits for its own stragglers before it
+// may start new camera rays; (2) at the end of the launch the workgroup's wavefronts finish the last units together
+// instead of each finishing two of its own.  The image is the same bit for bit: sums are exact and order-free.
+//   slot (8 words): x0, y0 (global row), ly0 (local row), next sample to trace, samples not yet finished, open flag
+//   ctl: [0] slot the camera rays are taken from (POOL_NONE before the first unit, POOL_DRAINED when the launch's
+//        counter has run out), [1] lock of the wavefront that is opening a unit
+//   LDS: [geo S float4][geo0 S float4][slots NS x 8 u32][ctl 4 u32][accumulators NS x P x 3 u64] then per wavefront
+//        [candidate lists RT_Q_CAND_CAP x 64 u16][queue RT_Q_WORDS x 64 u32]
+// A finished sample is added to its pixel's accumulators and then taken off its slot's count (LDS operations of a
+// wavefront are performed in order); whoever takes the last one off writes the unit's pixels and frees the slot.
+#define POOL_NONE 0xffffffffu
+#define POOL_DRAINED 0xfffffffeu
+
+RT_DEV uint32_t uniform_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
+// Opens the workgroup's next unit and makes it the one camera rays are taken from, if nobody else is at it.
+// ahead = POOL_NONE: the caller found the current unit used up (or none there yet).  ahead = a slot: the caller holds
+// a batch of that slot's unit, which is about to be used up: the next unit is opened early, so that the wavefronts
+// do not find themselves without camera rays for the time the launch's counter takes to answer; wavefronts go on
+// taking the older unit's last batches from the slot they remember (pool_next_batch).
+// Returns true if it makes sense to look at the control word again right away.
+RT_DEV bool pool_open(const RtLaunch& L, uint32_t* slots, uint32_t* ctl, uint32_t* __restrict__ work, uint32_t n_samp,
+                      uint32_t lane, uint32_t ahead, bool& drained) {
+    uint32_t lock = 1u;
+    if (lane == 0u) lock = atomicCAS(&ctl[1], 0u, 1u);
+    if (uniform_u32(lock) != 0u) return false;                    // somebody is opening one
+    // With the lock held nobody else opens a unit.
+    const uint32_t c = uniform_u32(__hip_atomic_load(&ctl[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
+    bool go;
+    if (ahead != POOL_NONE) {
+        go = c == ahead;          // still the newest (it cannot have changed hands: the caller holds a batch of it)
+    } else {
+        // If one was opened in the meantime (possibly in the very slot the caller saw, freed and taken again), its
+        // samples come first.
+        go = c == POOL_NONE || uniform_u32(__hip_atomic_load(&slots[c * 8u + 3u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) >= n_samp;
+    }
+    bool again = !go;
+    if (go) {
+        const bool is_free = lane < L.pool_slots && __hip_atomic_load(&slots[lane * 8u + 5u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u;
+        const unsigned long long free_mask = __ballot(is_free);
+        if (free_mask != 0ull) {                                  // else: every slot still has paths in flight
+            const uint32_t f = (uint32_t)__ffsll((long long)free_mask) - 1u;
+            uint32_t unit = 0u;
+            if (lane == 0u) unit = atomicAdd(work, 1u);
+            unit = uniform_u32(unit);
+            if (unit >= L.n_units) {
+                // no more units.  Opened early, the older unit's last batches are still out: its slot stays the
+                // current one, and whoever finds it used up comes here again and sets the end mark.
+                if (ahead == POOL_NONE) {
+                    if (lane == 0u) __hip_atomic_store(&ctl[0], POOL_DRAINED, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    drained = true;
+                }
+            } else {
+                const Slot u = open_unit(L, unit, n_samp);
+                if (lane == 0u) {
+                    slots[f * 8u + 0u] = u.x0;
+                    slots[f * 8u + 1u] = u.y0;
+                    slots[f * 8u + 2u] = u.ly0;
+                    slots[f * 8u + 4u] = n_samp;
+                    slots[f * 8u + 5u] = 1u;
+                    __hip_atomic_store(&slots[f * 8u + 3u], 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_store(&ctl[0], f, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                again = true;
+            }
+        }
+    }
+    if (lane == 0u) __hip_atomic_store(&ctl[1], 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return again;
+}
+
+// Takes the workgroup's next camera-ray batch: slot, first sample and the slot's first words (x0, y0, ly0).  False:
+// none to be had right now (the current unit is used up and another wavefront is opening the next one, every slot is
+// still held by unfinished paths, or the launch's counter has run out: `drained`).
+// ahead_at: the wavefront whose batch contains this sample of a unit opens the next unit (pool_open).
+RT_DEV bool pool_next_batch(const RtLaunch& L, uint32_t* slots, uint32_t* ctl, uint32_t* __restrict__ work, uint32_t n_samp,
+                            uint32_t ahead_at, uint32_t lane, uint32_t& hint, uint32_t& slot, uint32_t& first, uint4& head,
+                            bool& drained) {
+    bool got = false;
+    // The slot this wavefront last took a batch from is tried first.  A unit that still has untraced samples is good
+    // to take from whatever the control word says (a slot's counter is set to 0 only after its other fields, and
+    // stays at or above the unit's samples once they are used up); the first failure drops the hint, which bounds
+    // what waiting wavefronts add to a used-up counter.
+    if (hint != POOL_NONE) {
+        uint32_t old = 0u;
+        if (lane == 0u) old = __hip_atomic_fetch_add(&slots[hint * 8u + 3u], 64u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        // The slot's first words are read behind the atomic without waiting for it in between: the LDS performs a
+        // wavefront's operations in order, and once the batch is this wavefront's the slot cannot change hands.
+        asm volatile("" ::: "memory");
+        head = *reinterpret_cast<const uint4*>(slots + hint * 8u);
+        old = uniform_u32(old);
+        if (old < n_samp) { slot = hint; first = old; got = true; }
+        else hint = POOL_NONE;
+    }
+    for (int attempt = 0; attempt < 2 && !got; attempt++) {
+        const uint32_t c = uniform_u32(__hip_atomic_load(&ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+        if (c == POOL_DRAINED) { drained = true; return false; }
+        if (c != POOL_NONE) {
+            // look before taking: a used-up unit's counter must not be pushed round its 32 bits by waiting wavefronts
+            const uint32_t seen = uniform_u32(__hip_atomic_load(&slots[c * 8u + 3u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+            if (seen < n_samp) {
+                uint32_t old = 0u;
+                if (lane == 0u) old = __hip_atomic_fetch_add(&slots[c * 8u + 3u], 64u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+                old = uniform_u32(old);
+                if (old < n_samp) {
+                    slot = c; first = old; hint = c;
+                    head = *reinterpret_cast<const uint4*>(slots + c * 8u);
+                    got = true;
+                    break;
+                }
+            }
+        }
+        // the current unit is used up (or there is none yet): open the next one, if nobody else is at it
+        if (!pool_open(L, slots, ctl, work, n_samp, lane, POOL_NONE, drained)) return false;
+    }
+    if (got && ahead_at >= first && ahead_at < first + 64u) {
+        bool unused = false;
+        (void)pool_open(L, slots, ctl, work, n_samp, lane, slot, unused);
+    }
+    return got;
+}
+
+// Slot `sl`'s samples are all finished (wave-uniform call): writes the unit's pixels and frees the slot.
+RT_DEV void pool_write(const RtLaunch& L, uint32_t* slots, unsigned long long* accum, uint32_t sl, uint32_t lane,
+                       uint32_t* __restrict__ rgba, float4* __restrict__ linear) {
+    const uint32_t P = L.unit_w * L.unit_h;
+    Slot u;
+    u.open = true; u.left = 0u;
+    u.x0 = uniform_u32(slots[sl * 8u + 0u]);
+    u.y0 = uniform_u32(slots[sl * 8u + 1u]);
+    u.ly0 = uniform_u32(slots[sl * 8u + 2u]);
+    write_unit(L, u, accum + sl * 3u * P, lane, true, rgba, linear);
+    if (lane == 0u) __hip_atomic_store(&slots[sl * 8u + 5u], 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// `n` samples of slot `sl` are finished (wave-uniform call): takes them off the slot's count; if they were the last,
+// writes the unit's pixels and frees the slot.
+RT_DEV void pool_finish(const RtLaunch& L, uint32_t* slots, unsigned long long* accum, uint32_t sl, uint32_t n, uint32_t lane,
+                        uint32_t* __restrict__ rgba, float4* __restrict__ linear) {
+    uint32_t old = 0u;
+    if (lane == 0u) old = __hip_atomic_fetch_sub(&slots[sl * 8u + 4u], n, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (uniform_u32(old) == n) pool_write(L, slots, accum, sl, lane, rgba, linear);
+}
+
+RT_DEV void render_pool_body(const Scene& sc, uint32_t* __restrict__ rgba, float4* __restrict__ linear,
+                             unsigned long long* __restrict__ segments, uint32_t* __restrict__ work,
+                             const float4* __restrict__ camterms, const RtCamera& cam, const RtLaunch& L) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint64_t seed = ((uint64_t)L.seed_hi << 32) | L.seed_lo;
+    const uint32_t P = L.unit_w * L.unit_h;
+    const uint32_t n_samp = P * L.samples_per_pixel;              // per unit (the launcher keeps max_depth = 0 off this kernel)
+    const uint32_t S = L.n_padded, NS = L.pool_slots;
+    const V3 T = ld3(L.translate);
+
+    float4* geo = rt_lds;
+    float4* geo0 = rt_lds + S;
+    uint32_t* slots = reinterpret_cast<uint32_t*>(geo0 + S);
+    uint32_t* ctl = slots + NS * 8u;
+    unsigned long long* accum = reinterpret_cast<unsigned long long*>(ctl + 4u);
+    char* mine = reinterpret_cast<char*>(accum + NS * 3u * P) + wave * (RT_Q_CAND_CAP * 128u + RT_Q_WORDS * 256u);
+    Cand cand;
+    cand.col = reinterpret_cast<uint16_t*>(mine) + lane;
+    cand.n = 0u;
+    cand.cap = RT_Q_CAND_CAP;
+    uint32_t* q = reinterpret_cast<uint32_t*>(mine + RT_Q_CAND_CAP * 128u);
+    for (uint32_t k = threadIdx.x; k < NS * 8u; k += blockDim.x) slots[k] = (k & 7u) == 3u ? 0x80000000u : 0u;   // closed: used up
+    if (threadIdx.x == 0u) { ctl[0] = POOL_NONE; ctl[1] = 0u; }
+    for (uint32_t k = threadIdx.x; k < NS * 3u * P; k += blockDim.x) accum[k] = 0ull;
+    for (uint32_t i = threadIdx.x; i < S; i += blockDim.x) {
+        geo[i] = sc.geom[i];
+        geo0[i] = camterms[i];
+    }
+    __syncthreads();
+    const Tile tile = {geo, sc.exact};
+
+    Stats st;
+    bool drained = false;
+    uint32_t hint = POOL_NONE;
+    // the next unit is opened when about one batch per wavefront is left of the current one
+    const uint32_t ahead_at = n_samp > blockDim.x ? n_samp - blockDim.x : 0u;
+    uint32_t q_head = 0u, q_count = 0u;
+    bool need = true, active = false;
+    Path p;
+    p.o = v3(0.0f, 0.0f, 0.0f); p.d = v3(0.0f, 0.0f, 1.0f); p.thr = v3(1.0f, 1.0f, 1.0f); p.seg = 0u; p.nb = 0u;
+    uint32_t pixel = 0u, s = 0u, pixslot = 0u, nseg = 0u;
+    float band = 0.0f;
+
+    for (;;) {
+        // lanes without a path take queued rays
+        unsigned long long want = __ballot(need);
+        if (want != 0ull && q_head < q_count) {
+            const uint32_t j = q_head + __builtin_amdgcn_mbcnt_hi((uint32_t)(want >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)want, 0u));
+            if (need && j < q_count) {
+                p.o = v3(__uint_as_float(q[j]), __uint_as_float(q[64u + j]), __uint_as_float(q[128u + j]));
+                p.d = v3(__uint_as_float(q[192u + j]), __uint_as_float(q[256u + j]), __uint_as_float(q[320u + j]));
+                s = q[384u + j];
+                const uint32_t meta = q[448u + j];
+                const uint32_t sphere = meta & 0xffffu, ps = meta >> 16;
+                const uint32_t sl = ps >> 6, pix = ps & 63u;
+                const uint32_t dx = pix & (L.unit_w - 1u), dy = pix >> L.unit_shift;
+                const uint2 at = *reinterpret_cast<const uint2*>(slots + sl * 8u);
+                const uint32_t x = at.x + dx, y = at.y + dy;
+                pixel = y * L.width + x;
+                pixslot = 3u * pix + sl * 3u * P;
+                p.seg = 1u;
+                if (L.flags & RT_FLAG_BAND_ALBEDO) {
+                    band = band_of(L, x);
+                    p.nb = 1u;
+                } else {
+                    const float4 al = sc.shade[2u * sphere + 1u];
+                    p.thr = v3(al.x, al.y, al.z);                // 1 * albedo (ray.cu:37)
+                    p.nb = 0u;
+                }
+                need = false;
+                active = true;
+            }
+            const uint32_t asked = (uint32_t)__popcll(want);
+            q_head += asked < q_count - q_head ? asked : q_count - q_head;
+            want = __ballot(need);
+        }
+        // lanes still without one (the queue is empty now): trace the workgroup's next camera rays, then come round again
+        if (want != 0ull && !drained) {
+            uint32_t sl = 0u, first = 0u;
+            uint4 head = make_uint4(0u, 0u, 0u, 0u);
+            if (pool_next_batch(L, slots, ctl, work, n_samp, ahead_at, lane, hint, sl, first, head, drained)) {
+                Slot u;
+                u.open = true; u.left = 0u;
+                u.x0 = uniform_u32(head.x);
+                u.y0 = uniform_u32(head.y);
+                u.ly0 = uniform_u32(head.z);
+                uint32_t completed = 0u;
+                primary_batch(sc, tile, geo0, cam, L, seed, T, u, sl, first, n_samp, accum, nullptr, q, cand, q_count, completed, nseg, st);
+                q_head = 0u;
+                if (completed) pool_finish(L, slots, accum, sl, completed, lane, rgba, linear);
+                continue;
+            }
+        }
+
+        if (__ballot(active) == 0ull) {
+            // nothing to trace: done if the launch has no more units (open ones are finished by whoever holds their paths);
+            // otherwise wait a moment for a slot or for the wavefront that is opening the next unit
+            if (drained) break;
+            __builtin_amdgcn_s_sleep(4);
+        }
+
+        bool finished = false;                                   // this lane's path ended in this round
+        st.lap(14);
+        if (active) {
+            Best b;
+            b.t = L.t_max;
+            b.idx = -1;
+            scan_tile(tile, S, 0, T, p.o, p.d, vdot(p.d, p.d), L.t_min, b, cand, st);
+            nseg++;
+            V3 color;
+            if (shade_segment(sc, L, seed, b, pixel, s, band, p, color, st)) {
+                add_sample(accum, P, pixslot, s, L.samples_per_pixel, color, nullptr);
+                active = false;
+                need = true;
+                finished = true;
+            }
+        }
+        // Finished samples come off their units' counts.  A wavefront's lanes hold paths of a few units: the first
+        // finished lane of each unit takes all of that unit's off, all of them in one LDS instruction (an atomic per
+        // lane on the same word would cost the LDS a cycle per lane); whoever takes a unit's last ones writes the unit.
+        unsigned long long fin = __ballot(finished);
+        if (fin != 0ull) {
+            const uint32_t myslot = ((pixslot * 43691u) >> 17) >> L.unit_pshift;   // pixslot / 3 (exact below 98,304) / P
+            uint32_t mine_n = 0u;                                 // > 0: this lane takes that many off its unit
+            do {
+                const uint32_t l0 = (uint32_t)__ffsll((long long)fin) - 1u;
+                const uint32_t sl = (uint32_t)__builtin_amdgcn_readlane((int)myslot, (int)l0);
+                const unsigned long long same = __ballot(finished && myslot == sl);
+                if (lane == l0) mine_n = (uint32_t)__popcll(same);
+                fin &= ~same;
+            } while (fin != 0ull);
+            uint32_t before = 0u;
+            if (mine_n != 0u) before = __hip_atomic_fetch_sub(&slots[myslot * 8u + 4u], mine_n, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+            unsigned long long last = __ballot(mine_n != 0u && before == mine_n);
+            while (last != 0ull) {
+                const uint32_t l0 = (uint32_t)__ffsll((long long)last) - 1u;
+                pool_write(L, slots, accum, (uint32_t)__builtin_amdgcn_readlane((int)myslot, (int)l0), lane, rgba, linear);
+                last &= last - 1ull;
+            }
         }
     }
 
@@ -1326,6 +1633,15 @@ rt_render_queue_stream(const float4* geom, const float4* exact, const float4* sh
                        RtCamera cam, RtLaunch L) {
     Scene sc = {geom, exact, shade, mat};
     render_queue_stream_body<false>(sc, rgba, linear, segments, work, fold, camterms, cam, L);
+}
+
+// rt_render_queue with the pixel units held by the workgroup (render_pool_body).
+extern "C" __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6)))
+rt_render_pool(const float4* geom, const float4* exact, const float4* shade, const uint32_t* mat, uint32_t* rgba,
+               float4* linear, unsigned long long* segments, uint32_t* work, float4* fold, const float4* camterms,
+               RtCamera cam, RtLaunch L) {
+    Scene sc = {geom, exact, shade, mat};
+    render_pool_body(sc, rgba, linear, segments, work, camterms, cam, L);
 }
 
 // The same two kernels in fold-order mode (RtParams.sample_chunk = 0): finished samples are parked in the

@@ -32,19 +32,29 @@ def psnr(a, b):
 
 
 def check_render(oracle, hip, cam, spheres, params, exact=True, row0=0, rows=None):
+    """Renders on the GPU and compares with the checker.  sample_chunk = 1 has two schedulers (each wavefront holding
+    its own pixel units, or the workgroup a pool of them; the library picks by launch size): both are run and
+    checked, the pool last (its result is returned)."""
     hip.upload_scene(spheres)
-    got = hip.render(cam, params, row0=row0, rows=rows, linear=True)
     ocam = oracle.camera_f32_from_rt(cam.block)
     rgba, lin, seg = oracle.render(ocam, spheres, params, row0=row0, rows=rows)
-    err = np.abs(got["linear"].astype(np.float64) - lin.astype(np.float64))
-    assert np.isfinite(got["linear"]).all()
-    assert err.max() <= TOL_LINEAR, f"max abs linear error {err.max()} at {np.unravel_index(err.argmax(), err.shape)}"
-    assert psnr(got["rgba"], rgba) >= MIN_PSNR_DB
-    if exact:
-        bad = (got["linear"].view(np.uint32) != lin.view(np.uint32)).any(axis=-1)
-        assert not bad.any(), f"{bad.sum()} pixels differ in bits; max abs {err.max()}"
-        assert np.array_equal(got["rgba"], rgba)
-        assert got["rays"] == seg
+    for scheduler in (("wave", "pool") if params.sample_chunk == 1 else ("auto",)):
+        if scheduler != "auto":
+            hip.debug_schedule(scheduler=scheduler)
+        try:
+            got = hip.render(cam, params, row0=row0, rows=rows, linear=True)
+        finally:
+            if scheduler != "auto":
+                hip.debug_schedule()
+        err = np.abs(got["linear"].astype(np.float64) - lin.astype(np.float64))
+        assert np.isfinite(got["linear"]).all(), scheduler
+        assert err.max() <= TOL_LINEAR, f"{scheduler}: max abs linear error {err.max()} at {np.unravel_index(err.argmax(), err.shape)}"
+        assert psnr(got["rgba"], rgba) >= MIN_PSNR_DB, scheduler
+        if exact:
+            bad = (got["linear"].view(np.uint32) != lin.view(np.uint32)).any(axis=-1)
+            assert not bad.any(), f"{scheduler}: {bad.sum()} pixels differ in bits; max abs {err.max()}"
+            assert np.array_equal(got["rgba"], rgba), scheduler
+            assert got["rays"] == seg, scheduler
     return got, (rgba, lin, seg)
 
 
@@ -249,8 +259,9 @@ def test_camera_ray_batches_edge_cases(oracle, rt, hip):
     """sample_chunk = 1 runs the kernel that traces camera rays 64 at a time and feeds bounce rays from a queue.
     Against the checker, bit for bit: the CPU app's defaults (per-column reflectance, rounding quantiser), ragged
     frame sizes and every block size, the grid sampler, depth limits 0, 1 and 2 (a path that ends at its first
-    hit never enters the queue), a scene without spheres, one sample per pixel, a single row; and the same frame
-    from the item kernel (rt_debug_schedule no_queue) and from other unit shapes."""
+    hit never enters the queue), a scene without spheres, one sample per pixel, a single row -- each with the pixel
+    units held per wavefront and pooled per workgroup (check_render); and the same frame from the item kernel
+    (rt_debug_schedule no_queue) and from other unit shapes under both schedulers."""
     check_render(oracle, hip, rt.Camera.new_cpu(16.0 / 9.0, 256), rt.scene_cpu_default(), rt.cpu_params(64, 20, seed=0, sample_chunk=1))
     for width, block in ((250, 64), (67, 1024), (9, 0), (130, 320)):
         cam = rt.Camera.new(16.0 / 9.0, width)
@@ -266,13 +277,24 @@ def test_camera_ray_batches_edge_cases(oracle, rt, hip):
     p = rt.DeviceGUI(samples_per_pixel=24, max_depth=30, seed=8, sample_chunk=1)
     got, _ = check_render(oracle, hip, cam, sp, p)
     check_render(oracle, hip, cam, sp, p, row0=41, rows=1)
-    for unit, no_queue, kernel in ((None, True, "rt_render"), ((8, 8), False, "rt_render_queue"), ((16, 1), False, "rt_render_queue"),
-                                   ((1, 1), False, "rt_render_queue")):
-        hip.debug_schedule(unit=unit, no_queue=no_queue)
+    assert hip.last_kernel_name() == "rt_render_pool"
+    for unit, no_queue, scheduler, kernel in ((None, True, "auto", "rt_render"), (None, False, "auto", "rt_render_pool"),
+                                              ((8, 8), False, "wave", "rt_render_queue"), ((16, 1), False, "wave", "rt_render_queue"),
+                                              ((1, 1), False, "wave", "rt_render_queue"), ((8, 8), False, "pool", "rt_render_pool"),
+                                              ((16, 1), False, "pool", "rt_render_pool"), ((1, 1), False, "pool", "rt_render_pool"),
+                                              ((2, 2), False, "pool", "rt_render_pool")):
+        hip.debug_schedule(unit=unit, no_queue=no_queue, scheduler=scheduler)
         other = hip.render(cam, p, linear=True)
         assert hip.last_kernel_name() == kernel
         hip.debug_schedule()
-        assert np.array_equal(other["linear"], got["linear"]) and other["rays"] == got["rays"]
+        assert np.array_equal(other["linear"], got["linear"]) and other["rays"] == got["rays"], (unit, scheduler)
+    # depth 0 traces nothing: no pool to run
+    hip.debug_schedule(scheduler="pool")
+    hip.render(cam, rt.DeviceGUI(samples_per_pixel=6, max_depth=0, sample_chunk=1))
+    assert hip.last_kernel_name() == "rt_render_queue"
+    hip.debug_schedule()
+    with pytest.raises(rt.RtError):
+        hip._check(hip._lib.rt_debug_schedule(hip._ctx, 0, 0, 0, 7))
     with pytest.raises(rt.RtError):
         hip.debug_schedule(unit=(3, 1))
 
@@ -281,7 +303,7 @@ def test_camera_ray_scan_with_hostile_cameras(oracle, rt, hip):
     """The camera-ray scan works from per-sphere terms computed for the launch's camera (rt_camera_terms): cameras
     inside a glass sphere, on a sphere's surface, just above the huge ground sphere, far from the origin (the whole
     scene moved by 1e4), with a very narrow and a very wide field of view -- every sample its own item
-    (rt_render_queue) and the streamed kernel, bit for bit against the checker."""
+    (rt_render_queue, rt_render_pool) and the streamed kernel, bit for bit against the checker."""
     rng = np.random.default_rng(77)
 
     def scene(n, shift=(0.0, 0.0, 0.0)):
@@ -309,7 +331,7 @@ def test_camera_ray_scan_with_hostile_cameras(oracle, rt, hip):
     for name, sp, lookfrom, lookat, vfov in cases:
         cam = rt.Camera.look_at(16.0 / 9.0, 96, vfov, lookfrom, lookat)
         got, _ = check_render(oracle, hip, cam, sp, p)
-        assert hip.last_kernel_name() == ("rt_render_queue_stream" if len(sp) > 1024 else "rt_render_queue"), name
+        assert hip.last_kernel_name() == ("rt_render_queue_stream" if len(sp) > 1024 else "rt_render_pool"), name
         hits = hip.primary_hits(cam, p)
         ref = oracle.primary_hits(oracle.camera_f32_from_rt(cam.block), sp, p.t_min, p.t_max, p.flags)
         assert np.array_equal(hits, ref), name
@@ -504,6 +526,33 @@ def test_unit_size_does_not_change_the_image(rt, hip):
         assert np.array_equal(f["linear"], frames[0]["linear"]) and f["rays"] == frames[0]["rays"]
 
 
+def test_scheduler_is_chosen_by_launch_size_and_does_not_change_the_image(rt, hip):
+    """With every sample its own item the library pools the pixel units per workgroup on launches with few units per
+    resident wavefront and leaves them with the wavefronts on large ones.  921,600 one-pixel units are a large
+    launch, the same frame in the library's own units a small one; forced either way the frame is the same, for
+    workgroups of one wavefront (a pool of two units) up to sixteen, and for units with fewer samples than a
+    camera-ray batch."""
+    sp = rt.scene_book1_final(1)
+    cam = rt.Camera.look_at(16.0 / 9.0, 1280, 20.0, (13.0, 2.0, 3.0), (0.0, 0.0, 0.0))
+    p = rt.DeviceGUI(samples_per_pixel=2, max_depth=12, seed=6, sample_chunk=1)
+    hip.upload_scene(sp)
+    small = hip.render(cam, p, linear=True)
+    assert hip.last_kernel_name() == "rt_render_pool"
+    hip.debug_schedule(unit=(1, 1))
+    large = hip.render(cam, p, linear=True)
+    assert hip.last_kernel_name() == "rt_render_queue"
+    hip.debug_schedule()
+    assert np.array_equal(small["linear"], large["linear"]) and small["rays"] == large["rays"]
+    for block in (64, 128, 320, 1024):
+        for unit in ((1, 1), (4, 1), None):
+            p.block_dim = block
+            hip.debug_schedule(unit=unit, scheduler="pool")
+            other = hip.render(cam, p, linear=True)
+            assert hip.last_kernel_name() == "rt_render_pool"
+            hip.debug_schedule()
+            assert np.array_equal(other["linear"], small["linear"]) and other["rays"] == small["rays"], (block, unit)
+
+
 def test_rows_are_partition_invariant(rt, hip):
     """Any row range renders the same pixels as the full frame (RNG keyed on the global pixel index)."""
     sp = rt.scene_book1_final(1)
@@ -525,13 +574,23 @@ def test_rows_are_partition_invariant(rt, hip):
 
 def test_interleaved_tiles_into_device_memory(rt, hip):
     """The multi-GPU row mapping: ranks render interleaved 8-row tiles into compact device buffers; put back
-    together they are the single-launch image."""
+    together they are the single-launch image -- in fold order, and with every sample its own item under both
+    schedulers (pixel units held per wavefront, pooled per workgroup)."""
     torch = pytest.importorskip("torch")
     sp = rt.scene_book1_final(1)
     cam = rt.Camera.look_at(16.0 / 9.0, 136, 20.0, (13.0, 2.0, 3.0), (0.0, 0.0, 0.0))   # H = 76: last tile ragged
-    p = rt.DeviceGUI(samples_per_pixel=3, max_depth=10, seed=4)
     hip.upload_scene(sp)
-    full = hip.render(cam, p, linear=True)
+    for chunk, scheduler, kernel in ((0, "auto", "rt_render_queue_fold"), (1, "wave", "rt_render_queue"), (1, "pool", "rt_render_pool")):
+        p = rt.DeviceGUI(samples_per_pixel=3, max_depth=10, seed=4, sample_chunk=chunk)
+        full = hip.render(cam, p, linear=True)
+        hip.debug_schedule(scheduler=scheduler)
+        try:
+            _interleaved_tiles_equal_the_frame(torch, hip, cam, p, full, kernel)
+        finally:
+            hip.debug_schedule()
+
+
+def _interleaved_tiles_equal_the_frame(torch, hip, cam, p, full, kernel):
     W, H, TR = cam.image_width, cam.image_height, 8
     n_tiles = (H + TR - 1) // TR
     for world in (2, 3):
@@ -543,6 +602,7 @@ def test_interleaved_tiles_into_device_memory(rt, hip):
             d_rgba = torch.zeros((len(mine) * TR, W, 4), dtype=torch.uint8, device="cuda")
             d_lin = torch.zeros((len(mine) * TR, W, 4), dtype=torch.float32, device="cuda")
             r, _ = hip.render_tiles_device(cam, p, TR, rank, world, len(mine), d_rgba.data_ptr(), d_lin.data_ptr())
+            assert hip.last_kernel_name() == kernel
             rays += r
             h_rgba, h_lin = d_rgba.cpu().numpy(), d_lin.cpu().numpy()
             for k, t in enumerate(mine):

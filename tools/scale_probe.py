@@ -12,9 +12,9 @@ sp = rt.scene_book1_final(1)
 cam = rt.Camera.look_at(16 / 9, 3840, 20.0, (13, 2, 3), (0, 0, 0))
 p = rt.DeviceGUI(samples_per_pixel=spp, max_depth=50, seed=1, sample_chunk=int(os.environ.get('RT_CHUNK', '0')))
 w = rt.HipWorld(0, sp)
-# scheduling experiments, from the environment of the A/B scripts: RT_UNIT=WxH, RT_NO_QUEUE=1
+# scheduling experiments, from the environment of the A/B scripts: RT_UNIT=WxH, RT_NO_QUEUE=1, RT_SCHED=wave|pool
 _u = os.environ.get("RT_UNIT")
-w.debug_schedule(unit=tuple(int(v) for v in _u.split("x")) if _u else None, no_queue=os.environ.get("RT_NO_QUEUE") == "1")
+w.debug_schedule(unit=tuple(int(v) for v in _u.split("x")) if _u else None, no_queue=os.environ.get("RT_NO_QUEUE") == "1", scheduler=os.environ.get("RT_SCHED", "auto"))
 hs = os.environ.get("RT_HSACO")
 if hs:
     w.load_module(open(hs, "rb").read())
