@@ -237,14 +237,29 @@ RtLaunch make_launch(const rt_ctx* c, const RtCamera* cam, const RtParams* p, ui
         auto n_units_with = [&](uint32_t w, uint32_t h) {
             return (uint64_t)((cam->image_width + w - 1u) / w) * ((rows_local + h - 1u) / h);
         };
-        while (L.unit_w * L.unit_h < 64u) {
-            const uint64_t items = (uint64_t)L.unit_w * L.unit_h * L.n_chunks, samples = (uint64_t)L.unit_w * L.unit_h * spp;
-            uint32_t w = L.unit_w, h = L.unit_h;
-            if (w < 16u || !height_ok(2u * h)) w *= 2u; else h *= 2u;
-            if (items >= 512u && (samples >= 2048u || n_units_with(w, h) < 80u * resident)) break;
-            L.unit_w = w; L.unit_h = h;
+        auto grow = [&](uint64_t min_units) {
+            L.unit_w = 4u; L.unit_h = 1u;
+            while (L.unit_w * L.unit_h < 64u) {
+                const uint64_t items = (uint64_t)L.unit_w * L.unit_h * L.n_chunks, samples = (uint64_t)L.unit_w * L.unit_h * spp;
+                uint32_t w = L.unit_w, h = L.unit_h;
+                if (w < 16u || !height_ok(2u * h)) w *= 2u; else h *= 2u;
+                if (items >= 512u && (samples >= 2048u || n_units_with(w, h) < min_units)) break;
+                L.unit_w = w; L.unit_h = h;
+            }
+        };
+        // Launches that are small even in units of 2,048 samples (fewer than 64 per resident wavefront) run with the
+        // units pooled per workgroup (rt_render_pool, see launch_render), where the end of the launch costs little and
+        // the units can have their full size: 1080p book scene at 128 spp, pooled, 64 ms with 8x1 or 16x1 units, 72 ms
+        // with 4x1.
+        const bool pool_able = !fold && L.chunk == 1u && L.n_chunks > 1u && queue_kernel_fits(c, spp) && p->max_depth > 0u &&
+                               c->n_padded <= RT_TILE_SPHERES && c->f_render_pool != nullptr && c->dbg_scheduler != RT_SCHED_WAVE;
+        grow(0u);
+        if (pool_able && (n_units_with(L.unit_w, L.unit_h) < 64u * resident || c->dbg_scheduler == RT_SCHED_POOL)) L.pool_slots = 1u;
+        else grow(80u * resident);
+        if (c->dbg_unit_w && height_ok(c->dbg_unit_h)) {                                                        // rt_debug_schedule
+            L.unit_w = c->dbg_unit_w; L.unit_h = c->dbg_unit_h;
+            if (pool_able && c->dbg_scheduler == RT_SCHED_AUTO) L.pool_slots = n_units_with(L.unit_w, L.unit_h) < 64u * resident ? 1u : 0u;
         }
-        if (c->dbg_unit_w && height_ok(c->dbg_unit_h)) { L.unit_w = c->dbg_unit_w; L.unit_h = c->dbg_unit_h; }   // rt_debug_schedule
         // fold-order workspace: 2 units x P pixels x spp colours of 16 bytes per wavefront, at most 32 wavefronts per
         // compute unit resident; beyond 8 GiB the fold stays on the one-lane-per-pixel kernel
         const uint64_t fold_bytes = (uint64_t)(c->compute_units > 0 ? c->compute_units : 256) * 32u * 2u * L.unit_w * L.unit_h * spp * 16u;
@@ -312,11 +327,8 @@ int launch_render(rt_ctx* c, const RtCamera* cam, const RtParams* p, RtLaunch L,
         // from a quarter of the 4K frame down (1/8: 2 %, 1/16: 18 %; 1080p at 128 spp: 7 %), on the mirror hall at
         // 1080p (21 units per resident wavefront) but not at 4K (84).  Hence: the pool below 64 units per resident
         // wavefront (24 per compute unit).
-        bool pool = one_tile && !L.fold && L.max_depth > 0u && c->f_render_pool != nullptr &&
-                    (uint64_t)L.n_units < 64ull * 24u * (uint64_t)(c->compute_units > 0 ? c->compute_units : 256);
-        if (c->dbg_scheduler == RT_SCHED_WAVE) pool = false;
-        if (c->dbg_scheduler == RT_SCHED_POOL) pool = one_tile && !L.fold && L.max_depth > 0u && c->f_render_pool != nullptr;
-        if (pool) {
+        // (decided with the unit shape, in make_launch)
+        if (L.pool_slots != 0u) {
             f = c->f_render_pool;
             c->last_kernel = "rt_render_pool";
             // as many open units as the wavefronts would hold between them, so the same LDS: slot headers, the

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Counters of the per-wavefront and the workgroup-pool schedulers side by side on one box:
-#   bash tools/pmc_pool.sh <tag> "<quick_bench args>" <pool sizes...>     (pool size 0 = per-wavefront units)
+#   bash tools/pmc_pool.sh <tag> "<quick_bench args>" <schedulers...>     (wave = per-wavefront units, pool, auto)
 set -e
 TAG=$1; ARGS=$2; shift 2
 REPO=$(pwd)
@@ -8,11 +8,11 @@ OUT=$REPO/gpurun_out/pmc_pool_$TAG
 rm -rf "$OUT" "$OUT.txt"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp RT_CHUNK=${RT_CHUNK:-1}
 for n in "$@"; do
-  export RT_POOL=$n
+  export RT_SCHED=$n
   timeout -s KILL 200 rocprofv3 --pmc ${PMC:-SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE} \
-      --output-format csv -d "$OUT/pool$n" -- python3 "$REPO/tools/quick_bench.py" $ARGS > "$OUT/pool$n.log" 2>&1
-  echo "== pool $n" >> "$OUT.txt"
-  tail -1 "$OUT/pool$n.log" | sed 's/.*kernel/kernel/' >> "$OUT.txt"
-  python3 "$REPO/tools/pmc_summary.py" "$OUT/pool$n" rt_render >> "$OUT.txt"
+      --output-format csv -d "$OUT/$n" -- python3 "$REPO/tools/quick_bench.py" $ARGS > "$OUT/$n.log" 2>&1
+  echo "== $n" >> "$OUT.txt"
+  tail -1 "$OUT/$n.log" | sed 's/.*kernel/kernel/' >> "$OUT.txt"
+  python3 "$REPO/tools/pmc_summary.py" "$OUT/$n" rt_render >> "$OUT.txt"
 done
 cat "$OUT.txt"
