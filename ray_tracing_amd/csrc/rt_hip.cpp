@@ -312,9 +312,9 @@ int launch_render(rt_ctx* c, const RtCamera* cam, const RtParams* p, RtLaunch L,
             f = one_tile ? c->f_render_queue : c->f_render_queue_stream;
             c->last_kernel = one_tile ? "rt_render_queue" : "rt_render_queue_stream";
         }
-        if (one_tile && !L.fold && p->block_dim == 0u) {
-            // rt_render_queue is built for six waves per SIMD; with 512-thread workgroups three of them (24 wavefronts)
-            // fit a compute unit's LDS on the 485-sphere scene, with 256 threads only five (20 wavefronts)
+        if (one_tile && p->block_dim == 0u) {
+            // the one-tile kernels are built for six waves per SIMD; with 512-thread workgroups three of them (24
+            // wavefronts) fit a compute unit's LDS on the 485-sphere scene, with 256 threads only five (20 wavefronts)
             block = 512u;
             waves = block / 64u;
             grid = (L.n_units + waves - 1u) / waves;

@@ -1647,7 +1647,7 @@ rt_render_pool(const float4* geom, const float4* exact, const float4* shade, con
 // The same two kernels in fold-order mode (RtParams.sample_chunk = 0): finished samples are parked in the
 // wavefront's workspace and added in sample order in fp32 when their unit is complete -- the reference's
 // summation order (ray.cu:123-129, lib.rs:228-231) at the speed of the exact-accumulation kernels.
-extern "C" __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(5)))
+extern "C" __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6)))
 rt_render_queue_fold(const float4* geom, const float4* exact, const float4* shade, const uint32_t* mat, uint32_t* rgba,
                      float4* linear, unsigned long long* segments, uint32_t* work, float4* fold, const float4* camterms,
                      RtCamera cam, RtLaunch L) {

@@ -44,5 +44,5 @@ for it in range(3):
     flops = r["rays"] * (18 * n + 64)
     print(f"{scene} {cam.image_width}x{cam.image_height} spp={spp} depth={depth} n={n}: rays={r['rays']} "
           f"({r['rays'] / (cam.image_width * cam.image_height * spp):.2f}/sample) kernel {ms:.2f} ms wall {dt * 1e3:.1f} ms "
-          + (f"stats {w.debug_counters()[:9]} [15]={w.debug_counters()[15]} cycle shares {sections(w.debug_counters())} " if hs and "stats" in hs else "") +
+          + (f"stats {w.debug_counters()[:9]} [15]={w.debug_counters()[15]} cycle shares {sections(w.debug_counters())} " if hs and ("stats" in hs or "diag" in hs) else "") +
           f"crc {crc:08x} {w.last_kernel_name()} -> {r['rays'] / ms * 1e-3:.1f} Mrays/s, {flops / ms * 1e-9:.2f} TFLOP/s ({flops / ms * 1e-9 / 157.3 * 100:.1f}% of 157.3)", flush=True)
