@@ -134,12 +134,13 @@ int rt_show_random(rt_ctx *ctx, uint32_t width, uint32_t height, uint64_t seed, 
 
 /* Milliseconds the last render kernel took on the GPU (hipEvent pair around the launch). */
 float rt_last_kernel_ms(const rt_ctx *ctx);
-/* Name of the kernel the last render launched (rt_render, rt_render_stream, rt_render_queue,
+/* Name of the kernel the last render launched (rt_render, rt_render_stream, rt_render_queue, rt_render_pool,
  * rt_render_queue_stream, rt_render_queue_fold or rt_render_queue_stream_fold), for profiles. */
 const char *rt_last_kernel_name(const rt_ctx *ctx);
 
 /* Diagnostic: the 16 64-bit counters of the last render that asked for rays_out.  out[0] = ray segments;
- * out[8] = pixel units handed out (+ one failed request per wavefront).  The others are filled only by a code
+ * out[8] = pixel units handed out (+ the requests that found none left: one per wavefront, or a few per
+ * workgroup on rt_render_pool).  The others are filled only by a code
  * object built with -DRT_STATS: 1..7 loop-trip counts (scan passes, candidates listed, exact-test rounds,
  * decode rounds, unit-vector tries, drain calls, unit-vector rounds), 9..15 shader cycles per kernel section
  * (scan filter of bounce rays, decode, exact tests, hit + scatter, sky / accumulate, hand-out + queue + camera-ray
