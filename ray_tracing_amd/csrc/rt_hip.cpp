@@ -39,7 +39,7 @@ struct rt_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipModule_t module = nullptr;
-    hipFunction_t f_render = nullptr, f_render_queue = nullptr, f_render_queue_fold = nullptr, f_render_queue_stream_fold = nullptr, f_render_stream = nullptr, f_render_queue_stream = nullptr, f_hits = nullptr, f_random = nullptr, f_assemble = nullptr, f_camera_terms = nullptr, f_render_pool = nullptr;
+    hipFunction_t f_render = nullptr, f_render_queue = nullptr, f_render_queue_fold = nullptr, f_render_queue_stream_fold = nullptr, f_render_stream = nullptr, f_render_queue_stream = nullptr, f_hits = nullptr, f_random = nullptr, f_assemble = nullptr, f_camera_terms = nullptr, f_render_pool = nullptr, f_render_pool_fold = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     void *d_geom = nullptr, *d_exact = nullptr, *d_shade = nullptr, *d_mat = nullptr;
     void* d_camterms = nullptr;         // per sphere {A, B, C, sq} of the camera-ray scan, rewritten by every launch (rt_camera_terms)
@@ -154,6 +154,7 @@ int load_image(rt_ctx* c, const void* image) {
     if (c->module) (void)hipModuleUnload(c->module);
     c->module = m;
     if (hipModuleGetFunction(&c->f_render_pool, m, "rt_render_pool") != hipSuccess) { c->f_render_pool = nullptr; (void)hipGetLastError(); }
+    if (hipModuleGetFunction(&c->f_render_pool_fold, m, "rt_render_pool_fold") != hipSuccess) { c->f_render_pool_fold = nullptr; (void)hipGetLastError(); }
     c->f_render_queue_fold = fqf; c->f_render_queue_stream_fold = fqsf; c->f_render = fr; c->f_render_queue = fq; c->f_render_queue_stream = fqs; c->f_render_stream = fs; c->f_hits = fh; c->f_random = fx; c->f_assemble = fa; c->f_camera_terms = fct;
     return 0;
 }
@@ -251,8 +252,9 @@ RtLaunch make_launch(const rt_ctx* c, const RtCamera* cam, const RtParams* p, ui
         // units pooled per workgroup (rt_render_pool, see launch_render), where the end of the launch costs little and
         // the units can have their full size: 1080p book scene at 128 spp, pooled, 64 ms with 8x1 or 16x1 units, 72 ms
         // with 4x1.
-        const bool pool_able = !fold && L.chunk == 1u && L.n_chunks > 1u && queue_kernel_fits(c, spp) && p->max_depth > 0u &&
-                               c->n_padded <= RT_TILE_SPHERES && c->f_render_pool != nullptr && c->dbg_scheduler != RT_SCHED_WAVE;
+        const bool pool_able = L.chunk == 1u && L.n_chunks > 1u && queue_kernel_fits(c, spp) && p->max_depth > 0u &&
+                               c->n_padded <= RT_TILE_SPHERES && (fold ? c->f_render_pool_fold : c->f_render_pool) != nullptr &&
+                               c->dbg_scheduler != RT_SCHED_WAVE;
         grow(0u);
         if (pool_able && (n_units_with(L.unit_w, L.unit_h) < 64u * resident || c->dbg_scheduler == RT_SCHED_POOL)) L.pool_slots = 1u;
         else grow(80u * resident);
@@ -264,7 +266,7 @@ RtLaunch make_launch(const rt_ctx* c, const RtCamera* cam, const RtParams* p, ui
         // compute unit resident; beyond 8 GiB the fold stays on the one-lane-per-pixel kernel
         const uint64_t fold_bytes = (uint64_t)(c->compute_units > 0 ? c->compute_units : 256) * 32u * 2u * L.unit_w * L.unit_h * spp * 16u;
         if (L.fold && fold_bytes > (8ull << 30)) {
-            L.fold = 0u; L.chunk = spp; L.n_chunks = 1; L.unit_w = L.unit_h = 8;
+            L.fold = 0u; L.chunk = spp; L.n_chunks = 1; L.unit_w = L.unit_h = 8; L.pool_slots = 0u;
         }
     }
     for (int k = 0; k < 3; k++) L.translate[k] = c->translate[k];
@@ -329,8 +331,8 @@ int launch_render(rt_ctx* c, const RtCamera* cam, const RtParams* p, RtLaunch L,
         // wavefront (24 per compute unit).
         // (decided with the unit shape, in make_launch)
         if (L.pool_slots != 0u) {
-            f = c->f_render_pool;
-            c->last_kernel = "rt_render_pool";
+            f = L.fold ? c->f_render_pool_fold : c->f_render_pool;
+            c->last_kernel = L.fold ? "rt_render_pool_fold" : "rt_render_pool";
             // as many open units as the wavefronts would hold between them, so the same LDS: slot headers, the
             // control words, the slots' accumulators, and per wavefront the candidate lists and the ray queue
             L.pool_slots = 2u * waves;

@@ -1252,30 +1252,35 @@ RT_DEV bool pool_next_batch(const RtLaunch& L, uint32_t* slots, uint32_t* ctl, u
 }
 
 // Slot `sl`'s samples are all finished (wave-uniform call): writes the unit's pixels and frees the slot.
+// fold (fold-order mode): the workgroup's [slot][pixel][sample] colours; they were stored by any of its wavefronts
+// before those took the samples off the slot's count (release), and are read here after the count was seen (acquire).
 RT_DEV void pool_write(const RtLaunch& L, uint32_t* slots, unsigned long long* accum, uint32_t sl, uint32_t lane,
-                       uint32_t* __restrict__ rgba, float4* __restrict__ linear) {
+                       uint32_t* __restrict__ rgba, float4* __restrict__ linear, const float4* fold) {
     const uint32_t P = L.unit_w * L.unit_h;
     Slot u;
     u.open = true; u.left = 0u;
     u.x0 = uniform_u32(slots[sl * 8u + 0u]);
     u.y0 = uniform_u32(slots[sl * 8u + 1u]);
     u.ly0 = uniform_u32(slots[sl * 8u + 2u]);
-    write_unit(L, u, accum + sl * 3u * P, lane, true, rgba, linear);
+    write_unit(L, u, accum + sl * 3u * P, lane, true, rgba, linear, fold ? fold + (size_t)sl * P * L.samples_per_pixel : nullptr);
     if (lane == 0u) __hip_atomic_store(&slots[sl * 8u + 5u], 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
 // `n` samples of slot `sl` are finished (wave-uniform call): takes them off the slot's count; if they were the last,
 // writes the unit's pixels and frees the slot.
 RT_DEV void pool_finish(const RtLaunch& L, uint32_t* slots, unsigned long long* accum, uint32_t sl, uint32_t n, uint32_t lane,
-                        uint32_t* __restrict__ rgba, float4* __restrict__ linear) {
+                        uint32_t* __restrict__ rgba, float4* __restrict__ linear, const float4* fold) {
+    if (fold) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // every lane's stored samples before lane 0's count
     uint32_t old = 0u;
     if (lane == 0u) old = __hip_atomic_fetch_sub(&slots[sl * 8u + 4u], n, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
-    if (uniform_u32(old) == n) pool_write(L, slots, accum, sl, lane, rgba, linear);
+    if (uniform_u32(old) == n) pool_write(L, slots, accum, sl, lane, rgba, linear, fold);
 }
 
+template <bool FOLD>
 RT_DEV void render_pool_body(const Scene& sc, uint32_t* __restrict__ rgba, float4* __restrict__ linear,
                              unsigned long long* __restrict__ segments, uint32_t* __restrict__ work,
-                             const float4* __restrict__ camterms, const RtCamera& cam, const RtLaunch& L) {
+                             float4* __restrict__ fold_all, const float4* __restrict__ camterms, const RtCamera& cam,
+                             const RtLaunch& L) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint64_t seed = ((uint64_t)L.seed_hi << 32) | L.seed_lo;
@@ -1295,6 +1300,8 @@ RT_DEV void render_pool_body(const Scene& sc, uint32_t* __restrict__ rgba, float
     cand.n = 0u;
     cand.cap = RT_Q_CAND_CAP;
     uint32_t* q = reinterpret_cast<uint32_t*>(mine + RT_Q_CAND_CAP * 128u);
+    // fold-order mode: this workgroup's [NS slots][P][samples_per_pixel] colours in the launch's workspace
+    float4* fold = FOLD ? fold_all + (size_t)blockIdx.x * ((size_t)NS * P * L.samples_per_pixel) : nullptr;
     for (uint32_t k = threadIdx.x; k < NS * 8u; k += blockDim.x) slots[k] = (k & 7u) == 3u ? 0x80000000u : 0u;   // closed: used up
     if (threadIdx.x == 0u) { ctl[0] = POOL_NONE; ctl[1] = 0u; }
     for (uint32_t k = threadIdx.x; k < NS * 3u * P; k += blockDim.x) accum[k] = 0ull;
@@ -1361,9 +1368,9 @@ RT_DEV void render_pool_body(const Scene& sc, uint32_t* __restrict__ rgba, float
                 u.y0 = uniform_u32(head.y);
                 u.ly0 = uniform_u32(head.z);
                 uint32_t completed = 0u;
-                primary_batch(sc, tile, geo0, cam, L, seed, T, u, sl, first, n_samp, accum, nullptr, q, cand, q_count, completed, nseg, st);
+                primary_batch(sc, tile, geo0, cam, L, seed, T, u, sl, first, n_samp, accum, fold, q, cand, q_count, completed, nseg, st);
                 q_head = 0u;
-                if (completed) pool_finish(L, slots, accum, sl, completed, lane, rgba, linear);
+                if (completed) pool_finish(L, slots, accum, sl, completed, lane, rgba, linear, fold);
                 continue;
             }
         }
@@ -1385,7 +1392,7 @@ RT_DEV void render_pool_body(const Scene& sc, uint32_t* __restrict__ rgba, float
             nseg++;
             V3 color;
             if (shade_segment(sc, L, seed, b, pixel, s, band, p, color, st)) {
-                add_sample(accum, P, pixslot, s, L.samples_per_pixel, color, nullptr);
+                add_sample(accum, P, pixslot, s, L.samples_per_pixel, color, fold);
                 active = false;
                 need = true;
                 finished = true;
@@ -1405,12 +1412,13 @@ RT_DEV void render_pool_body(const Scene& sc, uint32_t* __restrict__ rgba, float
                 if (lane == l0) mine_n = (uint32_t)__popcll(same);
                 fin &= ~same;
             } while (fin != 0ull);
+            if (FOLD) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the lanes' stored samples before the counts
             uint32_t before = 0u;
             if (mine_n != 0u) before = __hip_atomic_fetch_sub(&slots[myslot * 8u + 4u], mine_n, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
             unsigned long long last = __ballot(mine_n != 0u && before == mine_n);
             while (last != 0ull) {
                 const uint32_t l0 = (uint32_t)__ffsll((long long)last) - 1u;
-                pool_write(L, slots, accum, (uint32_t)__builtin_amdgcn_readlane((int)myslot, (int)l0), lane, rgba, linear);
+                pool_write(L, slots, accum, (uint32_t)__builtin_amdgcn_readlane((int)myslot, (int)l0), lane, rgba, linear, fold);
                 last &= last - 1ull;
             }
         }
@@ -1641,7 +1649,7 @@ rt_render_pool(const float4* geom, const float4* exact, const float4* shade, con
                float4* linear, unsigned long long* segments, uint32_t* work, float4* fold, const float4* camterms,
                RtCamera cam, RtLaunch L) {
     Scene sc = {geom, exact, shade, mat};
-    render_pool_body(sc, rgba, linear, segments, work, camterms, cam, L);
+    render_pool_body<false>(sc, rgba, linear, segments, work, nullptr, camterms, cam, L);
 }
 
 // The same two kernels in fold-order mode (RtParams.sample_chunk = 0): finished samples are parked in the
@@ -1653,6 +1661,15 @@ rt_render_queue_fold(const float4* geom, const float4* exact, const float4* shad
                      RtCamera cam, RtLaunch L) {
     Scene sc = {geom, exact, shade, mat};
     render_queue_body<true>(sc, rgba, linear, segments, work, fold, camterms, cam, L);
+}
+
+// rt_render_pool in fold-order mode: finished samples go to the workgroup's part of the workspace.
+extern "C" __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6)))
+rt_render_pool_fold(const float4* geom, const float4* exact, const float4* shade, const uint32_t* mat, uint32_t* rgba,
+                    float4* linear, unsigned long long* segments, uint32_t* work, float4* fold, const float4* camterms,
+                    RtCamera cam, RtLaunch L) {
+    Scene sc = {geom, exact, shade, mat};
+    render_pool_body<true>(sc, rgba, linear, segments, work, fold, camterms, cam, L);
 }
 
 extern "C" __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(5)))

@@ -31,14 +31,15 @@ def psnr(a, b):
     return float("inf") if mse == 0 else 10.0 * np.log10(255.0 ** 2 / mse)
 
 
-def check_render(oracle, hip, cam, spheres, params, exact=True, row0=0, rows=None):
-    """Renders on the GPU and compares with the checker.  sample_chunk = 1 has two schedulers (each wavefront holding
-    its own pixel units, or the workgroup a pool of them; the library picks by launch size): both are run and
-    checked, the pool last (its result is returned)."""
+def check_render(oracle, hip, cam, spheres, params, exact=True, row0=0, rows=None, as_scheduled=False):
+    """Renders on the GPU and compares with the checker.  sample_chunk = 1 and 0 have two schedulers (each wavefront
+    holding its own pixel units, or the workgroup a pool of them; the library picks by launch size): both are run and
+    checked, the pool last (its result is returned).  Where the launch runs on another kernel the setting is ignored.
+    as_scheduled: one render with the context's rt_debug_schedule settings left as the caller made them."""
     hip.upload_scene(spheres)
     ocam = oracle.camera_f32_from_rt(cam.block)
     rgba, lin, seg = oracle.render(ocam, spheres, params, row0=row0, rows=rows)
-    for scheduler in (("wave", "pool") if params.sample_chunk == 1 else ("auto",)):
+    for scheduler in (("wave", "pool") if params.sample_chunk in (0, 1) and not as_scheduled else ("auto",)):
         if scheduler != "auto":
             hip.debug_schedule(scheduler=scheduler)
         try:
@@ -381,12 +382,14 @@ def test_fold_order_runs_on_the_batch_kernels_and_on_the_pixel_kernel(oracle, rt
     cam = rt.Camera.look_at(16.0 / 9.0, 150, 20.0, (13.0, 2.0, 3.0), (0.0, 0.0, 0.0))
     p = rt.DeviceGUI(samples_per_pixel=24, max_depth=30, seed=8, sample_chunk=0)
     got, _ = check_render(oracle, hip, cam, sp, p)
-    assert hip.last_kernel_name() == "rt_render_queue_fold"
-    for unit in ((8, 8), (1, 1), (16, 1), (2, 2)):
-        hip.debug_schedule(unit=unit)
-        other = hip.render(cam, p, linear=True)
-        hip.debug_schedule()
-        assert np.array_equal(other["linear"].view(np.uint32), got["linear"].view(np.uint32)) and other["rays"] == got["rays"]
+    assert hip.last_kernel_name() == "rt_render_pool_fold"
+    for scheduler, kernel in (("wave", "rt_render_queue_fold"), ("pool", "rt_render_pool_fold")):
+        for unit in ((8, 8), (1, 1), (16, 1), (2, 2)):
+            hip.debug_schedule(unit=unit, scheduler=scheduler)
+            other = hip.render(cam, p, linear=True)
+            assert hip.last_kernel_name() == kernel
+            hip.debug_schedule()
+            assert np.array_equal(other["linear"].view(np.uint32), got["linear"].view(np.uint32)) and other["rays"] == got["rays"]
     hip.debug_schedule(no_queue=True)
     other = hip.render(cam, p, linear=True)
     assert hip.last_kernel_name() == "rt_render"
@@ -397,13 +400,13 @@ def test_fold_order_runs_on_the_batch_kernels_and_on_the_pixel_kernel(oracle, rt
     check_render(oracle, hip, cam, sp, rt.DeviceGUI(samples_per_pixel=5, max_depth=0))
     check_render(oracle, hip, cam, sp, p, row0=41, rows=3)
     check_render(oracle, hip, rt.Camera.new_cpu(16.0 / 9.0, 250), rt.scene_cpu_default(), rt.cpu_params(37, 20, seed=3))
-    assert hip.last_kernel_name() == "rt_render_queue_fold"
+    assert hip.last_kernel_name() == "rt_render_pool_fold"
     grid = rt.scene_grid(2, 48)
     gcam = rt.Camera.look_at(16.0 / 9.0, 96, 40.0, (0.0, 30.0, 80.0), (0.0, 0.0, 0.0))
     check_render(oracle, hip, gcam, grid, rt.DeviceGUI(samples_per_pixel=3, max_depth=8, seed=2))
     assert hip.last_kernel_name() == "rt_render_queue_stream_fold"
     hip.debug_schedule(no_queue=True)
-    check_render(oracle, hip, gcam, grid, rt.DeviceGUI(samples_per_pixel=3, max_depth=8, seed=2))
+    check_render(oracle, hip, gcam, grid, rt.DeviceGUI(samples_per_pixel=3, max_depth=8, seed=2), as_scheduled=True)
     assert hip.last_kernel_name() == "rt_render_stream"
     hip.debug_schedule()
 
@@ -580,7 +583,8 @@ def test_interleaved_tiles_into_device_memory(rt, hip):
     sp = rt.scene_book1_final(1)
     cam = rt.Camera.look_at(16.0 / 9.0, 136, 20.0, (13.0, 2.0, 3.0), (0.0, 0.0, 0.0))   # H = 76: last tile ragged
     hip.upload_scene(sp)
-    for chunk, scheduler, kernel in ((0, "auto", "rt_render_queue_fold"), (1, "wave", "rt_render_queue"), (1, "pool", "rt_render_pool")):
+    for chunk, scheduler, kernel in ((0, "wave", "rt_render_queue_fold"), (0, "pool", "rt_render_pool_fold"),
+                                     (1, "wave", "rt_render_queue"), (1, "pool", "rt_render_pool")):
         p = rt.DeviceGUI(samples_per_pixel=3, max_depth=10, seed=4, sample_chunk=chunk)
         full = hip.render(cam, p, linear=True)
         hip.debug_schedule(scheduler=scheduler)
