@@ -135,7 +135,7 @@ int rt_show_random(rt_ctx *ctx, uint32_t width, uint32_t height, uint64_t seed, 
 /* Milliseconds the last render kernel took on the GPU (hipEvent pair around the launch). */
 float rt_last_kernel_ms(const rt_ctx *ctx);
 /* Name of the kernel the last render launched (rt_render, rt_render_stream, rt_render_queue, rt_render_pool,
- * rt_render_queue_stream, rt_render_queue_fold or rt_render_queue_stream_fold), for profiles. */
+ * rt_render_queue_stream, rt_render_queue_fold, rt_render_pool_fold or rt_render_queue_stream_fold), for profiles. */
 const char *rt_last_kernel_name(const rt_ctx *ctx);
 
 /* Diagnostic: the 16 64-bit counters of the last render that asked for rays_out.  out[0] = ray segments;
@@ -150,9 +150,9 @@ int rt_debug_counters(rt_ctx *ctx, uint64_t out[16]);
 /* Diagnostic: scheduling experiments on this context.  unit_w x unit_h (powers of two, at most 64 pixels;
  * 0, 0 = the library's choice) forces the shape of the pixel units the wavefronts take when sample_chunk > 0;
  * no_queue != 0 keeps sample_chunk = 1 on the work-item kernel instead of the camera-ray-batch kernels;
- * scheduler picks, for sample_chunk = 1 on sphere lists that fit one LDS tile, who holds the open pixel units:
- * RT_SCHED_WAVE each wavefront two of its own (rt_render_queue), RT_SCHED_POOL the workgroup a pool shared by its
- * wavefronts (rt_render_pool), RT_SCHED_AUTO the library's choice by the size of the launch.  None of these
+ * scheduler picks, for sample_chunk = 1 and 0 on sphere lists that fit one LDS tile, who holds the open pixel units:
+ * RT_SCHED_WAVE each wavefront two of its own (rt_render_queue[_fold]), RT_SCHED_POOL the workgroup a pool shared by
+ * its wavefronts (rt_render_pool[_fold]), RT_SCHED_AUTO the library's choice by the size of the launch.  None of these
  * changes a single bit of the image (exact accumulation), only the timing.  No counterpart in the reference
  * beyond its block_dim slider (gui.rs:287). */
 #define RT_SCHED_AUTO 0

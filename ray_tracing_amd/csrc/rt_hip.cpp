@@ -323,12 +323,12 @@ int launch_render(rt_ctx* c, const RtCamera* cam, const RtParams* p, RtLaunch L,
         }
         lds = (one_tile ? c->n_padded : RT_Q_STREAM_TILE) * 32u + waves * (RT_Q_CAND_CAP * 128u + 48u * P + RT_Q_WORDS * 256u);
         // Who holds the open pixel units: each wavefront two of its own (rt_render_queue), or the workgroup a pool of
-        // them from which all its wavefronts take camera rays (rt_render_pool).  The pool costs more bookkeeping per
-        // batch (4K book scene, 500 spp: 1.2 % slower; 8K mirror hall: 8 %), but no wavefront waits for its own units'
-        // last paths and the launch's last units are finished by whole workgroups: measured on the book scene it wins
-        // from a quarter of the 4K frame down (1/8: 2 %, 1/16: 18 %; 1080p at 128 spp: 7 %), on the mirror hall at
-        // 1080p (21 units per resident wavefront) but not at 4K (84).  Hence: the pool below 64 units per resident
-        // wavefront (24 per compute unit).
+        // them from which all its wavefronts take camera rays (rt_render_pool).  The pool costs about 22 more
+        // instructions per batch and trip (4K book scene, 500 spp: 0.7 % slower; 8K mirror hall: 3.5 %), but no wavefront
+        // waits for its own units' last paths and the launch's last units are finished by whole workgroups: measured on
+        // the book scene it wins from a quarter of the 4K frame down (1/8: 3 %, 1/16: 12 %; 1080p at 128 spp: 23 % with
+        // full-size units), on the mirror hall at 1080p but not at 4K.  Hence: the pool below 64 full-size units per
+        // resident wavefront (24 per compute unit).
         // (decided with the unit shape, in make_launch)
         if (L.pool_slots != 0u) {
             f = L.fold ? c->f_render_pool_fold : c->f_render_pool;
