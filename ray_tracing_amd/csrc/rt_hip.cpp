@@ -248,7 +248,7 @@ RtLaunch make_launch(const rt_ctx* c, const RtCamera* cam, const RtParams* p, ui
                 L.unit_w = w; L.unit_h = h;
             }
         };
-        // Launches that are small even in units of 2,048 samples (fewer than 64 per resident wavefront) run with the
+        // Launches that are small even in units of 2,048 samples (fewer than 128 per resident wavefront) run with the
         // units pooled per workgroup (rt_render_pool, see launch_render), where the end of the launch costs little and
         // the units can have their full size: 1080p book scene at 128 spp, pooled, 64 ms with 8x1 or 16x1 units, 72 ms
         // with 4x1.
@@ -256,11 +256,11 @@ RtLaunch make_launch(const rt_ctx* c, const RtCamera* cam, const RtParams* p, ui
                                c->n_padded <= RT_TILE_SPHERES && (fold ? c->f_render_pool_fold : c->f_render_pool) != nullptr &&
                                c->dbg_scheduler != RT_SCHED_WAVE;
         grow(0u);
-        if (pool_able && (n_units_with(L.unit_w, L.unit_h) < 64u * resident || c->dbg_scheduler == RT_SCHED_POOL)) L.pool_slots = 1u;
+        if (pool_able && (n_units_with(L.unit_w, L.unit_h) < 128u * resident || c->dbg_scheduler == RT_SCHED_POOL)) L.pool_slots = 1u;
         else grow(80u * resident);
         if (c->dbg_unit_w && height_ok(c->dbg_unit_h)) {                                                        // rt_debug_schedule
             L.unit_w = c->dbg_unit_w; L.unit_h = c->dbg_unit_h;
-            if (pool_able && c->dbg_scheduler == RT_SCHED_AUTO) L.pool_slots = n_units_with(L.unit_w, L.unit_h) < 64u * resident ? 1u : 0u;
+            if (pool_able && c->dbg_scheduler == RT_SCHED_AUTO) L.pool_slots = n_units_with(L.unit_w, L.unit_h) < 128u * resident ? 1u : 0u;
         }
         // fold-order workspace: 2 units x P pixels x spp colours of 16 bytes per wavefront, at most 32 wavefronts per
         // compute unit resident; beyond 8 GiB the fold stays on the one-lane-per-pixel kernel
@@ -327,8 +327,9 @@ int launch_render(rt_ctx* c, const RtCamera* cam, const RtParams* p, RtLaunch L,
         // instructions per batch and trip (4K book scene, 500 spp: 0.7 % slower; 8K mirror hall: 3.5 %), but no wavefront
         // waits for its own units' last paths and the launch's last units are finished by whole workgroups: measured on
         // the book scene it wins from a quarter of the 4K frame down (1/8: 3 %, 1/16: 12 %; 1080p at 128 spp: 23 % with
-        // full-size units), on the mirror hall at 1080p but not at 4K.  Hence: the pool below 64 full-size units per
-        // resident wavefront (24 per compute unit).
+        // full-size units); on the mirror hall, whose paths run to 100 segments, an eighth of the 8K frame (84 units per
+        // resident wavefront) is 9 % faster pooled, a quarter 1 %, a half 2 % slower.  Hence: the pool below 128 full-size
+        // units per resident wavefront (24 per compute unit); the book scene's half frame, 84, is equal either way.
         // (decided with the unit shape, in make_launch)
         if (L.pool_slots != 0u) {
             f = L.fold ? c->f_render_pool_fold : c->f_render_pool;

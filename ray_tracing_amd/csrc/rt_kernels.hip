@@ -1624,7 +1624,7 @@ rt_render(const float4* geom, const float4* exact, const float4* shade, const ui
     render_body<false>(sc, rgba, linear, segments, work, cam, L);
 }
 
-// Six waves per SIMD (80 VGPRs, 12 of the path's registers parked in scratch around the camera-ray batch) instead of
+// Six waves per SIMD (77 VGPRs, nothing spilled) instead of
 // five: the launcher's default of 512-thread workgroups lets LDS hold 24 wavefronts per compute unit; measured on one
 // box against five waves and 256 threads: book scene 4K frame 950 -> 930 ms, deep-bounce hall 436 -> 420 ms.
 extern "C" __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6)))
