@@ -129,10 +129,16 @@ RT_DEV void accept_exact(float h, float ncc, float disc, float a, float t_min, i
     if (disc >= 0.0f && (h > 0.0f || ncc > 0.0f)) {
         float s = sqrtf(disc);
         float root_a = (h - s) / a;
-        float root_b = (h + s) / a;
         float root = root_a;
         bool ok = (t_min < root_a) && (root_a < b.t);
-        if (!ok) { root = root_b; ok = (t_min < root_b) && (root_b < b.t); }
+        // The far root is looked at only when the near one is not beyond t_min: otherwise the near one failed on the
+        // upper bound, and the far one, (h + s) / a >= (h - s) / a (s >= 0, a > 0; addition and division round
+        // monotonically), fails on it too -- its divide is skipped for most candidates.
+        if (!(t_min < root_a)) {
+            float root_b = (h + s) / a;
+            root = root_b;
+            ok = (t_min < root_b) && (root_b < b.t);
+        }
         if (ok) { b.t = root; b.idx = idx; }
     }
 }
