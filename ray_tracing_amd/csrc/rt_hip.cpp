@@ -248,19 +248,25 @@ RtLaunch make_launch(const rt_ctx* c, const RtCamera* cam, const RtParams* p, ui
                 L.unit_w = w; L.unit_h = h;
             }
         };
-        // Launches that are small even in units of 2,048 samples (fewer than 128 per resident wavefront) run with the
-        // units pooled per workgroup (rt_render_pool, see launch_render), where the end of the launch costs little and
-        // the units can have their full size: 1080p book scene at 128 spp, pooled, 64 ms with 8x1 or 16x1 units, 72 ms
-        // with 4x1.
+        // Launches that are small even in units of 2,048 samples run with the units pooled per workgroup (rt_render_pool,
+        // see launch_render), where the end of the launch costs little and the units can have their full size: 1080p
+        // book scene at 128 spp, pooled, 64 ms with 8x1 or 16x1 units, 72 ms with 4x1.  Small: fewer than 128 units per
+        // resident wavefront at max_depth 50, in proportion for other depths (between 64 and 512) -- the end of a launch
+        // lasts as long as its longest paths.  Measured: book scene (depth 50), half of the 4K frame = 84 units per
+        // wavefront equal either way, the whole = 169 0.7 % slower pooled; mirror hall (depth 100), a quarter of the 8K
+        // frame = 169 units per wavefront 1 % faster pooled, an eighth 9 %, half = 337 2 % slower.
+        uint64_t per_wave = (uint64_t)128u * p->max_depth / 50u;
+        per_wave = per_wave < 64u ? 64u : per_wave > 512u ? 512u : per_wave;
+        const uint64_t pool_below = per_wave * resident;
         const bool pool_able = L.chunk == 1u && L.n_chunks > 1u && queue_kernel_fits(c, spp) && p->max_depth > 0u &&
                                c->n_padded <= RT_TILE_SPHERES && (fold ? c->f_render_pool_fold : c->f_render_pool) != nullptr &&
                                c->dbg_scheduler != RT_SCHED_WAVE;
         grow(0u);
-        if (pool_able && (n_units_with(L.unit_w, L.unit_h) < 128u * resident || c->dbg_scheduler == RT_SCHED_POOL)) L.pool_slots = 1u;
+        if (pool_able && (n_units_with(L.unit_w, L.unit_h) < pool_below || c->dbg_scheduler == RT_SCHED_POOL)) L.pool_slots = 1u;
         else grow(80u * resident);
         if (c->dbg_unit_w && height_ok(c->dbg_unit_h)) {                                                        // rt_debug_schedule
             L.unit_w = c->dbg_unit_w; L.unit_h = c->dbg_unit_h;
-            if (pool_able && c->dbg_scheduler == RT_SCHED_AUTO) L.pool_slots = n_units_with(L.unit_w, L.unit_h) < 128u * resident ? 1u : 0u;
+            if (pool_able && c->dbg_scheduler == RT_SCHED_AUTO) L.pool_slots = n_units_with(L.unit_w, L.unit_h) < pool_below ? 1u : 0u;
         }
         // fold-order workspace: 2 units x P pixels x spp colours of 16 bytes per wavefront, at most 32 wavefronts per
         // compute unit resident; beyond 8 GiB the fold stays on the one-lane-per-pixel kernel
@@ -328,9 +334,8 @@ int launch_render(rt_ctx* c, const RtCamera* cam, const RtParams* p, RtLaunch L,
         // waits for its own units' last paths and the launch's last units are finished by whole workgroups: measured on
         // the book scene it wins from a quarter of the 4K frame down (1/8: 3 %, 1/16: 12 %; 1080p at 128 spp: 23 % with
         // full-size units); on the mirror hall, whose paths run to 100 segments, an eighth of the 8K frame (84 units per
-        // resident wavefront) is 9 % faster pooled, a quarter 1 %, a half 2 % slower.  Hence: the pool below 128 full-size
-        // units per resident wavefront (24 per compute unit); the book scene's half frame, 84, is equal either way.
-        // (decided with the unit shape, in make_launch)
+        // resident wavefront) is 9 % faster pooled, a quarter 1 %, a half 2 % slower.  Hence: the pool for launches with few
+        // full-size units per resident wavefront, decided with the unit shape in make_launch.
         if (L.pool_slots != 0u) {
             f = L.fold ? c->f_render_pool_fold : c->f_render_pool;
             c->last_kernel = L.fold ? "rt_render_pool_fold" : "rt_render_pool";

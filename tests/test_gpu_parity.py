@@ -531,7 +531,7 @@ def test_unit_size_does_not_change_the_image(rt, hip):
 
 def test_scheduler_is_chosen_by_launch_size_and_does_not_change_the_image(rt, hip):
     """With every sample its own item the library pools the pixel units per workgroup on launches with few units per
-    resident wavefront (fewer than 128) and leaves them with the wavefronts on large ones.  921,600 one-pixel units are a large
+    resident wavefront (fewer than 128 at max_depth 50, 64 at this test's 12) and leaves them with the wavefronts on large ones.  921,600 one-pixel units are a large
     launch, the same frame in the library's own units a small one; forced either way the frame is the same, for
     workgroups of one wavefront (a pool of two units) up to sixteen, and for units with fewer samples than a
     camera-ray batch."""
