@@ -556,6 +556,30 @@ def test_scheduler_is_chosen_by_launch_size_and_does_not_change_the_image(rt, hi
             assert np.array_equal(other["linear"], small["linear"]) and other["rays"] == small["rays"], (block, unit)
 
 
+def test_schedulers_agree_on_tiny_frames_and_odd_sample_counts(rt, hip):
+    """Frames of one pixel, one row, one column and a few more, 2 to 129 samples per pixel (a unit smaller than a
+    camera-ray batch, exactly one batch, one sample more), depth 1 and 50, workgroups of one and of sixteen
+    wavefronts, exact accumulation and fold order: the per-wavefront and the pooled scheduler, each with the library's
+    units, one-pixel units and 64x1 units, give the same frame and the same ray count bit for bit."""
+    import itertools
+    hip.upload_scene(rt.scene_book1_final(1))
+    for width, aspect in ((1, 1.0), (2, 1.0), (3, 3.0), (7, 0.2), (64, 16.0 / 9.0), (65, 64.0)):
+        cam = rt.Camera.look_at(aspect, width, 20.0, (13.0, 2.0, 3.0), (0.0, 0.0, 0.0))
+        for spp, depth, block, chunk in itertools.product((2, 3, 63, 64, 65, 129), (1, 50), (0, 64, 1024), (1, 0)):
+            p = rt.DeviceGUI(samples_per_pixel=spp, max_depth=depth, seed=spp + depth, block_dim=block, sample_chunk=chunk)
+            ref = None
+            for scheduler, unit in itertools.product(("wave", "pool"), (None, (1, 1), (64, 1))):
+                hip.debug_schedule(unit=unit, scheduler=scheduler)
+                r = hip.render(cam, p, linear=True)
+                name = hip.last_kernel_name()
+                hip.debug_schedule()
+                assert name.startswith("rt_render_pool" if scheduler == "pool" else "rt_render_queue"), name
+                if ref is None:
+                    ref = r
+                assert np.array_equal(r["linear"].view(np.uint32), ref["linear"].view(np.uint32)) and r["rays"] == ref["rays"], \
+                    (width, aspect, spp, depth, block, chunk, scheduler, unit)
+
+
 def test_rows_are_partition_invariant(rt, hip):
     """Any row range renders the same pixels as the full frame (RNG keyed on the global pixel index)."""
     sp = rt.scene_book1_final(1)
