@@ -8,13 +8,18 @@ interleaved 8-row tiles (rank r renders tiles r, r+N, ...; total work fixed = st
 finished tiles are gathered to rank 0 with RCCL inside the timed region.
 
     python bench.py                      # 1 GPU, defaults
+    python bench.py --gpus N             # starts its own N ranks (a child `python -m torch.distributed.run`)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
 Rank 0 prints one JSON line.  `value` counts every ray segment all ranks traced in the K timed steps
 (in-kernel counters) divided by the max-over-ranks wall time.  `roofline` prices the render kernel
 against the FP32 vector peak with the algorithmic FLOP count 18*N_spheres + 64 per segment and the
-kernel's own duration (HIP events on the launch stream, inside the library).  `cpu_baseline` times the
+kernel's own duration (HIP events on the launch stream, inside the library); that count is the algorithm's
+(a full ray-sphere test per sphere), not the instructions the kernel issues -- `roofline.executed` carries the
+hardware-side figures of the stamped profile under profiles/ when one matches the code object.  `e2e_*` is a
+separate, untimed-for-`value` leg: the same frame through the blocking host-frame entry point (kernel + D2H, what
+the reference's frame time contains).  `cpu_baseline` times the
 double-precision CPU restatement of the reference (oracle/, test infrastructure) on a bounded sample of
 the same scene on this host's cores.
 """
@@ -74,6 +79,8 @@ def parse():
                     help="samples per work item (RtParams.sample_chunk); 1 = every sample its own item (camera rays in batches); "
                          "0 = the reference's fp32 fold, one lane per pixel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--e2e-steps", type=int, default=2,
+                    help="frames of the separate end-to-end leg (kernel + copy of the frame to host memory); 0 = skip")
     ap.add_argument("--cpu-width", type=int, default=1920)
     ap.add_argument("--cpu-spp", type=int, default=32)
     return ap.parse_args()
@@ -101,9 +108,10 @@ def code_object_sha256():
     return hashlib.sha256(open(path, "rb").read()).hexdigest() if os.path.exists(path) else None
 
 
-def stamped_traffic(workload):
-    """HBM bytes per launch from a PMC profile kept under profiles/ -- only one taken with the code object this run
-    executes (SHA-256 stamp) AND on this workload (the profile records bench.py's own workload string)."""
+def stamped_profile(workload):
+    """The PMC profile kept under profiles/ -- only one taken with the code object this run executes (SHA-256
+    stamp) AND on this workload (the profile records bench.py's own workload string).  Returns (HBM bytes per
+    launch, executed-work figures or None)."""
     import glob
     sha = code_object_sha256()
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")), reverse=True):
@@ -112,8 +120,29 @@ def stamped_traffic(workload):
         except Exception:
             continue
         if sha and rec.get("code_object_sha256") == sha and rec.get("workload") == workload:
-            return rec.get("hbm_bytes_per_launch")
-    return None
+            return rec.get("hbm_bytes_per_launch"), rec.get("executed")
+    return None, None
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` started without a launcher: start the N ranks as a CHILD process (torch's own
+    launcher on 127.0.0.1) and exit with its code.  Runs before anything in this process has touched a GPU;
+    counting devices does not initialise one.  Rank 0's JSON line reaches stdout through the inherited handle."""
+    import socket
+    import subprocess
+    import torch
+    found = torch.cuda.device_count()
+    if found < args.gpus:
+        print(f"bench.py: needs {args.gpus} GPUs, found {found}", file=sys.stderr)
+        return 2
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -129,9 +158,12 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
-        if world == 1 and args.gpus > 1:
-            sys.exit(2)
+            print(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks", file=sys.stderr)
+        sys.exit(2)
+    found = torch.cuda.device_count()
+    if local_rank >= found:
+        print(f"bench.py: rank {rank} needs GPU {local_rank}; this node has {found} (needs {world} GPUs, found {found})", file=sys.stderr)
+        sys.exit(2)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -190,6 +222,32 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
 
+    # End-to-end leg, outside `value`: the frame as the reference's host receives it (CudaWorld::render launches and
+    # then copies the frame to host memory, blocking: gpu-implementation/src/ray_tracing.rs:200-208).  One GPU: the
+    # library's rt_render_rows into a host frame (kernel + D2H).  N GPUs: render + gather + assembly as above, then
+    # rank 0's copy of the assembled frame to host memory.
+    e2e_ms, d2h_ms = [], []
+    if args.e2e_steps > 0:
+        import numpy as np
+        host = np.empty((H, W, 4), np.uint8)
+        host_t = torch.from_numpy(host)
+        for k in range(args.e2e_steps + 1):                # the first one is a warm-up (device frame, page faults)
+            fence()
+            t = time.perf_counter()
+            if world == 1:
+                hip.render(cam, params, out=host)
+                t_d2h = 0.0
+            else:
+                _, _, _, _, f = step()
+                t1 = time.perf_counter()
+                if rank == 0:
+                    host_t.copy_(f)
+                t_d2h = (time.perf_counter() - t1) * 1e3
+            fence()
+            if k > 0:
+                e2e_ms.append((time.perf_counter() - t) * 1e3)
+                d2h_ms.append(t_d2h)
+
     mean = lambda v: sum(v) / max(1, len(v))
     stats = torch.tensor([elapsed, float(rays_total), mean(kernel_ms), mean(gather_ms)], dtype=torch.float64, device=dev)
     per_rank = None
@@ -218,7 +276,7 @@ def main():
         workload_text = (f"{args.workload}: {WORKLOADS[args.workload][0]}, {n_sph} spheres, {W}x{H}, {args.spp} spp, max depth {args.depth}, "
                          f"jittered sampler, seed 1, sample_chunk {args.sample_chunk}; frame split into interleaved {TILE_ROWS}-row tiles over "
                          f"{world} GPU(s), RCCL gather to rank 0")
-        traffic = stamped_traffic(workload_text) if world == 1 else None
+        traffic, executed = stamped_profile(workload_text) if world == 1 else (None, None)
         out = {
             "metric": "Mrays/s (primary+bounce) at 1/2/4/8 MI355X + % of FP32 VALU peak",
             "value": rays_all / elapsed_max * 1e-6,
@@ -238,12 +296,26 @@ def main():
             "roofline": {"bound": "valu_fp32", "achieved": achieved, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP32_VECTOR_PEAK_TFLOPS, "traffic": traffic,
                          "kernel": hip.last_kernel_name(), "kernel_ms": k_ms, "flop_per_segment": flop_per_segment,
-                         "segments_per_launch": rank0_rays_per_launch},
+                         "segments_per_launch": rank0_rays_per_launch,
+                         # what `achieved` counts: the algorithm's work (one full ray-sphere test to the discriminant,
+                         # 18 FLOP, per sphere and segment + 64 per segment), not the instructions issued -- the kernel
+                         # reaches the same hits with a conservative 9-operation (bounce rays) or 4-operation (camera
+                         # rays) filter per sphere and the full test on the few candidates
+                         "count": "algorithm-equivalent FLOP (18 per ray-sphere test x spheres + 64 per segment), not executed FLOP",
+                         # hardware-side figures of the PMC profile taken with this code object on this workload
+                         # (profiles/), or null: VALU lane-operations actually executed, and VALU issue slots used
+                         "executed": executed},
             "kernel_ms_max_over_ranks": kms_max,
             # where a multi-GPU step goes: each rank's own render kernel, its gather (on rank 0 this includes the
             # wait for the slowest rank, i.e. load imbalance and launch skew), rank 0's copy kernel
             "per_rank": per_rank,
             "rank0_gather_ms": mean(gather_ms), "rank0_assemble_ms": mean(assemble_ms),
+            # end-to-end leg (not part of `value`): frame in host memory; None when skipped
+            "e2e_ms_per_step": mean(e2e_ms) if e2e_ms else None,
+            "e2e_value": (rays_all / max(1, args.steps)) / (mean(e2e_ms) * 1e-3) * 1e-6 if e2e_ms else None,
+            "e2e_rank0_d2h_ms": mean(d2h_ms) if (e2e_ms and world > 1) else None,
+            "e2e_note": ("rt_render_rows: kernel + blocking copy of the RGBA8 frame to pageable host memory" if world == 1 else
+                         "render + RCCL gather + assembly + rank 0's copy of the frame to pageable host memory") if e2e_ms else None,
             "checksum": int(frame.to(torch.int64).sum().item()) if frame is not None else None,
         }
         if world == 1 and not args.no_cpu_baseline and args.workload == "c3":
@@ -257,4 +329,6 @@ def main():
 
 if __name__ == "__main__":
     ARGS = parse()
+    if ARGS.gpus > 1 and "WORLD_SIZE" not in os.environ and "LOCAL_RANK" not in os.environ:
+        sys.exit(spawn_ranks(ARGS))
     main()

@@ -113,7 +113,9 @@ int rt_comm_init(rt_ctx *ctx, const uint8_t id[RT_COMM_ID_BYTES], uint32_t world
  * (may be NULL) receives this rank's own segment count.  A context without rt_comm_init is rank 0 of 1.
  * Before any tile travels the ranks exchange one status word (4-byte all-reduce): if a rank failed locally
  * (allocation, launch), it returns its own error and every other rank returns RT_ERR_COMM instead of waiting
- * for it.  Arguments must be the same on all ranks. */
+ * for it.  A rank on which that exchange itself fails gives up its communicator (ncclCommAbort) and returns the
+ * error; the context then refuses further sharded renders (RT_ERR_COMM) -- make a new context and communicator.
+ * Arguments must be the same on all ranks. */
 int rt_render_frame_sharded(rt_ctx *ctx, const RtCamera *cam, const RtParams *params, uint32_t tile_rows,
                             uint8_t *frame_out, uint64_t *rays_out);
 /* The copy kernel of the gather by itself, for hosts that move the tile buffers with a transport of their own
@@ -159,6 +161,15 @@ int rt_debug_counters(rt_ctx *ctx, uint64_t out[16]);
 #define RT_SCHED_WAVE 1
 #define RT_SCHED_POOL 2
 int rt_debug_schedule(rt_ctx *ctx, uint32_t unit_w, uint32_t unit_h, int no_queue, int scheduler);
+
+/* Diagnostic: the largest fold-order workspace this context may allocate, in bytes (0 = the default, 8 GiB).
+ * RtParams.sample_chunk = 0 (the reference's summation order) runs on the camera-ray-batch kernels with a workspace of
+ * finished samples in device memory, owned by the context and allocated at the first such render:
+ *   resident wavefronts x 2 open units x pixels per unit x samples_per_pixel x 16 bytes
+ * (4K book scene at 500 spp: 5,120 x 2 x 4 x 500 x 16 B = 328 MB).  A launch whose workspace would exceed the limit,
+ * or cannot be allocated, runs on the one-lane-per-pixel kernel instead, which needs none: same image bit for bit,
+ * slower.  No counterpart in the reference (its kernel keeps one thread per pixel, ray.cu:109-129). */
+int rt_debug_fold_workspace_limit(rt_ctx *ctx, uint64_t bytes);
 
 /* Name and compute-unit count of the context's GPU. */
 int rt_device_info(const rt_ctx *ctx, char *name, size_t name_size, int *compute_units, int *clock_khz);

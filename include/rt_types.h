@@ -89,7 +89,10 @@ typedef struct RtParams {
     float    t_max;              /* +inf on the CPU path (lib.rs:193), 10024 on the GPU path (ray.cu:24) */
     uint32_t block_dim;          /* threads per workgroup, multiple of 64 in 64..1024 (ray_tracing.rs:59,190-192); 0 = library default */
     /* Accumulation of the samples of a pixel.
-     * 0: all samples are added in order in fp32, the reference's fold (lib.rs:228-231, ray.cu:123-129).
+     * 0: all samples are added in order in fp32, the reference's fold (lib.rs:228-231, ray.cu:123-129).  With two or
+     *    more samples per pixel this runs on the camera-ray-batch kernels too, which park finished samples in a device
+     *    workspace owned by the context (size and limit: rt_debug_fold_workspace_limit in rt_hip.h); without room for
+     *    it, on the one-lane-per-pixel kernel -- the same bits either way.
      * C > 0 (and C < samples_per_pixel): runs of C consecutive samples are added in order in fp32; the run sums are
      *    then added exactly (each converted to 2^-32 fixed point, 64-bit integer addition) and the mean is rounded
      *    once.  Exact addition is order-independent, so the runs of a pixel can be traced by any lane at any time:

@@ -215,11 +215,15 @@ class HipWorld:
         self._check(self._lib.rt_upload_scene(self._ctx, _ffi.ptr(w), len(w)))
         self.n_spheres = len(w)
 
-    def render(self, camera, params, row0=0, rows=None, linear=False, hits=False):
-        """Returns dict(rgba[rows,W,4] u8, rays, kernel_ms[, linear[rows,W,4] f32][, hits[rows,W] i32])."""
+    def render(self, camera, params, row0=0, rows=None, linear=False, hits=False, out=None):
+        """Returns dict(rgba[rows,W,4] u8, rays, kernel_ms[, linear[rows,W,4] f32][, hits[rows,W] i32]).
+        out: a caller-owned contiguous [rows,W,4] u8 array to receive the frame (`frame: &mut [u8]`,
+        ray_tracing.rs:163) instead of a fresh one."""
         W, H = camera.image_width, camera.image_height
         rows = H - row0 if rows is None else rows
-        rgba = np.empty((rows, W, 4), np.uint8)
+        if out is not None and (out.dtype != np.uint8 or out.shape != (rows, W, 4) or not out.flags["C_CONTIGUOUS"]):
+            raise ValueError("out must be a C-contiguous uint8 array of shape (rows, W, 4)")
+        rgba = out if out is not None else np.empty((rows, W, 4), np.uint8)
         lin = np.empty((rows, W, 4), np.float32) if linear else None
         hit = np.empty((rows, W), np.int32) if hits else None
         rays = C.c_uint64(0)
@@ -309,6 +313,11 @@ class HipWorld:
         w, h = unit if unit else (0, 0)
         self._check(self._lib.rt_debug_schedule(self._ctx, w, h, int(bool(no_queue)),
                                                 {"auto": 0, "wave": 1, "pool": 2}[scheduler]))
+
+    def debug_fold_workspace_limit(self, nbytes=0):
+        """Largest fold-order workspace (sample_chunk = 0 on the camera-ray-batch kernels) the context may allocate;
+        larger launches run on the one-lane-per-pixel kernel.  0 = the default (8 GiB)."""
+        self._check(self._lib.rt_debug_fold_workspace_limit(self._ctx, nbytes))
 
     def device_info(self):
         name = C.create_string_buffer(600)

@@ -57,10 +57,12 @@ struct rt_ctx {
     size_t cap_rgba = 0, cap_linear = 0, cap_hits = 0;
     void* d_fold = nullptr;             // fold-order workspace of the queue kernels: finished samples until their unit is complete
     size_t cap_fold = 0;
+    size_t fold_limit = (size_t)8 << 30; // largest fold-order workspace the context will allocate (rt_debug_fold_workspace_limit)
     // multi-GPU gather: this context is rank `rank` of `world`
     ncclComm_t comm = nullptr;
     uint32_t world = 1, rank = 0;
-    void* d_status = nullptr;                        // two 32-bit words for the ranks' status exchange (rt_comm_init)
+    void* d_status = nullptr;                        // three 32-bit words for the ranks' status exchange (rt_comm_init):
+                                                     // [0] this rank's status, [1] the all-reduce's result, [2] constant 1
     void *d_tiles = nullptr, *d_frame = nullptr;     // rank's tile buffer (rank 0: all ranks' buffers), assembled frame
     size_t cap_tiles = 0, cap_frame = 0;
     float last_ms = 0.0f;
@@ -269,9 +271,10 @@ RtLaunch make_launch(const rt_ctx* c, const RtCamera* cam, const RtParams* p, ui
             if (pool_able && c->dbg_scheduler == RT_SCHED_AUTO) L.pool_slots = n_units_with(L.unit_w, L.unit_h) < pool_below ? 1u : 0u;
         }
         // fold-order workspace: 2 units x P pixels x spp colours of 16 bytes per wavefront, at most 32 wavefronts per
-        // compute unit resident; beyond 8 GiB the fold stays on the one-lane-per-pixel kernel
+        // compute unit resident; beyond the context's limit (8 GiB unless changed) the fold stays on the
+        // one-lane-per-pixel kernel, which needs no workspace and adds the same samples in the same order
         const uint64_t fold_bytes = (uint64_t)(c->compute_units > 0 ? c->compute_units : 256) * 32u * 2u * L.unit_w * L.unit_h * spp * 16u;
-        if (L.fold && fold_bytes > (8ull << 30)) {
+        if (L.fold && fold_bytes > (uint64_t)c->fold_limit) {
             L.fold = 0u; L.chunk = spp; L.n_chunks = 1; L.unit_w = L.unit_h = 8; L.pool_slots = 0u;
         }
     }
@@ -362,8 +365,12 @@ int launch_render(rt_ctx* c, const RtCamera* cam, const RtParams* p, RtLaunch L,
     if (L.fold) {
         const size_t need = (size_t)grid * waves * 2u * P * L.samples_per_pixel * 16u;
         if (!fold_workspace) return fail(c, RT_ERR_INVALID, "internal: fold-order launch without a workspace");
-        int rc = ensure(c, &c->d_fold, &c->cap_fold, need);
-        if (rc) return rc;
+        if (need > c->fold_limit || ensure(c, &c->d_fold, &c->cap_fold, need) != 0) {
+            // No room for the workspace (hundreds of MB to several GB at high sample counts): the fold runs on the
+            // one-lane-per-pixel kernel instead, which needs none -- same bits, slower -- rather than failing.
+            RtLaunch plain = make_launch(c, cam, p, L.row_base, L.rows_local, L.tile_rows, L.tile_stride_rows, false);
+            return launch_render(c, cam, p, plain, d_rgba, d_linear, rays_out, counters, false);
+        }
         d_fold = c->d_fold;
     }
     // counter block: [0] path segments (+ diagnostics in [1..7]), 64-bit each; byte 64: the unit counter
@@ -406,6 +413,7 @@ struct Rccl {
     decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
     decltype(&ncclCommInitRank) CommInitRank = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclCommAbort) CommAbort = nullptr;
     decltype(&ncclSend) Send = nullptr;
     decltype(&ncclRecv) Recv = nullptr;
     decltype(&ncclGroupStart) GroupStart = nullptr;
@@ -444,6 +452,7 @@ void load_rccl(Rccl& r) {
     r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
     r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
     r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
+    r.CommAbort = reinterpret_cast<decltype(r.CommAbort)>(sym("ncclCommAbort"));
     r.Send = reinterpret_cast<decltype(r.Send)>(sym("ncclSend"));
     r.Recv = reinterpret_cast<decltype(r.Recv)>(sym("ncclRecv"));
     r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(sym("ncclGroupStart"));
@@ -770,7 +779,11 @@ int rt_comm_init(rt_ctx* c, const uint8_t id[RT_COMM_ID_BYTES], uint32_t world, 
     RT_HIP(c, hipSetDevice(c->device));
     ncclUniqueId u;
     std::memcpy(&u, id, sizeof u);
-    if (!c->d_status) RT_HIP(c, hipMalloc(&c->d_status, 8));
+    if (!c->d_status) {
+        RT_HIP(c, hipMalloc(&c->d_status, 12));
+        const int32_t init[3] = {0, 0, 1};
+        RT_HIP(c, hipMemcpy(c->d_status, init, sizeof init, hipMemcpyHostToDevice));
+    }
     RT_RCCL(c, r->CommInitRank(&c->comm, (int)world, u, (int)rank));
     c->world = world;
     c->rank = rank;
@@ -801,7 +814,7 @@ int rt_render_frame_sharded(rt_ctx* c, const RtCamera* cam, const RtParams* p, u
     if (rc) return rc;
     if ((rc = check_render(c, p))) return rc;
     if (tile_rows == 0 || tile_rows % 8u != 0) return fail(c, RT_ERR_INVALID, "tile_rows must be a positive multiple of 8");
-    if (c->world > 1 && !c->comm) return fail(c, RT_ERR_INVALID, "rt_comm_init has not been called");
+    if (c->world > 1 && !c->comm) return fail(c, RT_ERR_COMM, "this context's communicator was given up after a failed exchange; create a new context and communicator");
     const uint32_t W = cam->image_width, H = cam->image_height, world = c->world, rank = c->rank;
     const uint32_t rows_per_rank = tiles_of_rank(H, tile_rows, 0, world) * tile_rows;   // rank 0 owns the most tiles
     const size_t part = (size_t)rows_per_rank * W * 4;                                  // bytes every rank contributes
@@ -829,12 +842,27 @@ int rt_render_frame_sharded(rt_ctx* c, const RtCamera* cam, const RtParams* p, u
         Rccl* r = rccl();
         const int32_t mine_failed = local_rc ? 1 : 0;
         int32_t any_failed = 1;
+        char* status = static_cast<char*>(c->d_status);
+        // A rank that cannot even upload its status word still takes part, sending the constant 1 kept in word 2:
+        // its peers must not be left waiting in the all-reduce.
+        const void* send = status;
+        int upload_rc = 0;
         hipError_t e = hipMemcpyAsync(c->d_status, &mine_failed, 4, hipMemcpyHostToDevice, c->stream);
-        if (e != hipSuccess) return hip_fail(c, e, "hipMemcpyAsync(status)");
-        RT_RCCL(c, r->AllReduce(c->d_status, static_cast<char*>(c->d_status) + 4, 1, ncclInt32, ncclMax, c->comm, c->stream));
-        if ((e = hipMemcpyAsync(&any_failed, static_cast<char*>(c->d_status) + 4, 4, hipMemcpyDeviceToHost, c->stream)) != hipSuccess ||
+        if (e != hipSuccess) { upload_rc = hip_fail(c, e, "hipMemcpyAsync(status)"); send = status + 8; }
+        const std::string upload_err = c->err;
+        // If the exchange itself fails on this rank, nobody can tell any more who goes on to send tiles: the
+        // communicator is given up (ncclCommAbort releases operations of this rank that peers may be waiting in).
+        auto give_up = [&](int code) {
+            if (r->CommAbort) (void)r->CommAbort(c->comm); else (void)r->CommDestroy(c->comm);
+            c->comm = nullptr;
+            return code;
+        };
+        ncclResult_t ar = r->AllReduce(send, status + 4, 1, ncclInt32, ncclMax, c->comm, c->stream);
+        if (ar != ncclSuccess) return give_up(rccl_fail(c, ar, "ncclAllReduce(status)"));
+        if ((e = hipMemcpyAsync(&any_failed, status + 4, 4, hipMemcpyDeviceToHost, c->stream)) != hipSuccess ||
             (e = hipStreamSynchronize(c->stream)) != hipSuccess)
-            return hip_fail(c, e, "status exchange");
+            return give_up(hip_fail(c, e, "status exchange"));
+        if (upload_rc) return fail(c, upload_rc, upload_err);
         if (local_rc) return fail(c, local_rc, local_err);
         if (any_failed) return fail(c, RT_ERR_COMM, "rt_render_frame_sharded: another rank failed before the exchange; no tiles were sent");
     } else if (local_rc) {
@@ -866,6 +894,12 @@ int rt_render_frame_sharded(rt_ctx* c, const RtCamera* cam, const RtParams* p, u
         RT_HIP(c, hipMemcpyAsync(frame_out, c->d_frame, frame_bytes, hipMemcpyDeviceToHost, c->stream));
     }
     RT_HIP(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int rt_debug_fold_workspace_limit(rt_ctx* c, uint64_t bytes) {
+    if (!c) return RT_ERR_INVALID;
+    c->fold_limit = bytes ? (size_t)bytes : (size_t)8 << 30;
     return 0;
 }
 

@@ -214,3 +214,49 @@ def test_rust_crate_declares_only_exported_symbols():
             total += {"f32": 4, "u32": 4, "u64": 8}[m.group(1) if m else ty] * (int(m.group(2)) if m else 1)
         return total
     assert words("RtSphere") == 36 and words("RtCamera") == 148 and words("RtParams") == 40
+
+
+def test_fake_rccl_exports_what_the_library_binds():
+    """tests/native/libfake_rccl.so (test infrastructure for the multi-rank GPU test) must offer every RCCL entry
+    point rt_hip.cpp resolves at run time, or the library would refuse to load it."""
+    import ctypes as C
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "ray_tracing_amd", "csrc", "rt_hip.cpp")).read()
+    bound = set(re.findall(r'sym\("(nccl[A-Za-z]+)"\)', src))
+    assert {"ncclSend", "ncclRecv", "ncclAllReduce", "ncclCommAbort"} <= bound
+    path = os.path.join(root, "tests", "native", "libfake_rccl.so")
+    assert os.path.exists(path), "make -C tests/native"
+    nm = subprocess_output(["nm", "-D", "--defined-only", path])
+    for name in bound:
+        assert re.search(r"\bT %s\b" % name, nm), name
+
+
+def subprocess_output(cmd):
+    import subprocess
+    return subprocess.run(cmd, capture_output=True, text=True, check=True).stdout
+
+
+def test_bench_starts_its_own_ranks(monkeypatch, capsys):
+    """`python bench.py --gpus N` without a launcher: too few GPUs is a one-line error and exit code 2; with enough
+    GPUs it starts torch's launcher as a child process with N ranks on 127.0.0.1 and passes its own flags on."""
+    import sys
+    import types
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    import torch
+    args = types.SimpleNamespace(gpus=4)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
+    assert bench.spawn_ranks(args) == 2
+    assert "needs 4 GPUs, found 1" in capsys.readouterr().err
+    seen = {}
+    import subprocess
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 8)
+    monkeypatch.setattr(subprocess, "call", lambda cmd, env=None: seen.update(cmd=cmd, env=env) or 7)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "2"])
+    assert bench.spawn_ranks(args) == 7
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "127.0.0.1" in cmd
+    assert cmd[-4:] == ["--gpus", "4", "--steps", "2"] and cmd[-5].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"

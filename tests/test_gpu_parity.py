@@ -124,7 +124,10 @@ def test_against_the_f64_restatement_of_lib_rs(oracle, rt, hip):
     per-pixel comparison is made on the pixels whose path signatures agree (the single-precision checker supplies
     the GPU's signatures: the two are bit-identical) and the 8-bit images are compared by PSNR.  Asserted at the
     measured levels (PSNR over the colour channels): C1 62.9 dB / 6.4e-6, C2 band 71.3 dB / 7.8e-7, C3 at 240x135,
-    32 spp 50.9 dB / 6.4e-4."""
+    32 spp 50.9 dB / 6.4e-4.  The 1e-4 bar on linear radiance is met against the single-precision checker on the
+    same stream (error 0, asserted in `compare`), not against f64: on the book scene rounding differences grow from
+    bounce to bounce between hundreds of curved reflectors even while the sphere sequence stays the same, so that
+    comparison is asserted at 1e-3, just above what is observed."""
     def compare(cam, sp, p, row0=0, rows=None):
         hip.upload_scene(sp)
         got = hip.render(cam, p, row0=row0, rows=rows, linear=True)
@@ -141,7 +144,7 @@ def test_against_the_f64_restatement_of_lib_rs(oracle, rt, hip):
     assert share > 0.98 and err <= 1e-5 and db >= 65.0, (share, err, db)
     cam = rt.Camera.look_at(16.0 / 9.0, 240, 20.0, (13.0, 2.0, 3.0), (0.0, 0.0, 0.0))
     share, err, db = compare(cam, rt.scene_book1_final(1), rt.DeviceGUI(samples_per_pixel=32, max_depth=50, seed=11))
-    assert share > 0.75 and err <= 5e-3 and db >= MIN_PSNR_DB, (share, err, db)
+    assert share > 0.75 and err <= 1e-3 and db >= MIN_PSNR_DB, (share, err, db)
 
 
 def test_c2_hit_map_full_resolution(oracle, rt, hip):
@@ -156,6 +159,56 @@ def test_c2_hit_map_full_resolution(oracle, rt, hip):
     assert np.array_equal(hits, ref)
     assert (hits == 0).any() and (hits == 1).any() and (hits == -1).any()
     check_render(oracle, hip, cam, sp, p, row0=536, rows=8)
+
+
+def test_c2_full_size(oracle, rt, hip):
+    """The CPU crate's scene at its full 1920x1080, 100 spp, depth 50 (per-column reflectance bands, sign-bit flip
+    rule, rounding quantiser; lib.rs:225-238): the whole frame on the GPU as the library schedules it (pooled units),
+    two rows of it -- sphere and ground, and the ground near the bottom edge -- bit-exact against the checker, a band
+    rendered as a launch of its own with the checker's ray count, and the other scheduler giving the same frame."""
+    cam = rt.Camera.new_cpu(16.0 / 9.0, 1920)
+    sp = rt.scene_cpu_default()
+    p = rt.cpu_params(100, 50, seed=1, sample_chunk=1)
+    hip.upload_scene(sp)
+    full = hip.render(cam, p, linear=True)
+    assert hip.last_kernel_name() == "rt_render_pool"
+    assert full["linear"].shape == (1080, 1920, 4) and np.isfinite(full["linear"]).all()
+    assert (full["rgba"][..., 3] == 255).all() and full["rays"] > 1920 * 1080 * 100
+    ocam = oracle.camera_f32_from_rt(cam.block)
+    for row0 in (540, 1071):
+        rgba, lin, seg = oracle.render(ocam, sp, p, row0=row0, rows=1)
+        assert np.array_equal(full["linear"][row0:row0 + 1].view(np.uint32), lin.view(np.uint32)), row0
+        assert np.array_equal(full["rgba"][row0:row0 + 1], rgba)
+        band = hip.render(cam, p, row0=row0, rows=1)
+        assert band["rays"] == seg and np.array_equal(band["rgba"], rgba)
+    # the five reflectance bands of lib.rs:225-226 at W = 1920: the sky row's colour steps at every 384th column
+    sky_row = full["linear"][0, :, 0]
+    assert len(np.unique(sky_row[::384])) == 5
+    hip.debug_schedule(scheduler="wave")
+    other = hip.render(cam, p, linear=True)
+    hip.debug_schedule()
+    assert hip.last_kernel_name() == "rt_render_queue"
+    assert np.array_equal(other["linear"].view(np.uint32), full["linear"].view(np.uint32)) and other["rays"] == full["rays"]
+
+
+def test_fold_order_without_room_for_its_workspace(rt, hip):
+    """sample_chunk = 0 on the camera-ray-batch kernels needs a workspace of finished samples; a launch whose workspace
+    would exceed the context's limit runs on the one-lane-per-pixel kernel instead of failing -- same bits."""
+    sp = rt.scene_book1_final(1)
+    cam = rt.Camera.look_at(16.0 / 9.0, 150, 20.0, (13.0, 2.0, 3.0), (0.0, 0.0, 0.0))
+    p = rt.DeviceGUI(samples_per_pixel=24, max_depth=30, seed=8, sample_chunk=0)
+    hip.upload_scene(sp)
+    want = hip.render(cam, p, linear=True)
+    assert hip.last_kernel_name() == "rt_render_pool_fold"
+    hip.debug_fold_workspace_limit(4096)
+    try:
+        got = hip.render(cam, p, linear=True)
+        assert hip.last_kernel_name() == "rt_render"
+    finally:
+        hip.debug_fold_workspace_limit(0)
+    assert np.array_equal(got["linear"].view(np.uint32), want["linear"].view(np.uint32)) and got["rays"] == want["rays"]
+    hip.render(cam, p)
+    assert hip.last_kernel_name() == "rt_render_pool_fold"
 
 
 def test_gpu_default_scene_grid_sampler(oracle, rt, hip):

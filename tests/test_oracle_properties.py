@@ -315,6 +315,47 @@ def test_unit_vector_sampler_is_uniform_on_the_sphere(oracle):
     assert np.abs(hist - m / 20).max() < 5 * np.sqrt(m / 20)
 
 
+def test_unit_vector_lattice_sampler_against_a_continuous_one(oracle):
+    """One rejection try cuts ONE 32-bit generator output into three lattice coordinates (11, 11 and 10 bits: z has
+    half the resolution of x and y), where the reference draws three independent uniforms per try (lib.rs:33-39,
+    library.cu:18-24).  A deliberate deviation; this checks that it does not show in the distribution of directions:
+    against a continuous sampler (numpy, 24-bit uniforms, the same rejection rule) on 150,000 directions each --
+    moments of cos(theta) about every axis (1st..4th: 0, 1/3, 0, 1/5), the azimuth about every axis (histogram and
+    first two harmonics), and two-sample Kolmogorov-Smirnov tests between the coarse axis and the fine ones and
+    between the two samplers."""
+    from scipy import stats
+    n = 150_000
+    v = np.array([oracle.unit_vector((1234, p, s, 1)) for p in range(n // 100) for s in range(100)])
+    rng = np.random.default_rng(5)
+    c = np.empty((0, 3))
+    while len(c) < n:                                             # the continuous sampler
+        q = (rng.integers(0, 1 << 24, (n, 3)) * 2.0 ** -24) * 2.0 - 1.0
+        q = q[(q * q).sum(axis=1) <= 1.0]
+        q = q[(q * q).sum(axis=1) > 0.0]
+        c = np.concatenate([c, q / np.linalg.norm(q, axis=1, keepdims=True)])
+    c = c[:n]
+    sig = 5.0 / np.sqrt(n)                                        # five standard errors of a mean of O(1) terms
+    for name, w in (("lattice", v), ("continuous", c)):
+        for axis in range(3):
+            z = w[:, axis]
+            assert abs(z.mean()) < sig * np.sqrt(1 / 3), (name, axis)
+            assert abs((z ** 2).mean() - 1 / 3) < sig * np.sqrt(4 / 45), (name, axis)
+            assert abs((z ** 3).mean()) < sig * np.sqrt(1 / 7), (name, axis)
+            assert abs((z ** 4).mean() - 1 / 5) < sig * np.sqrt(1 / 9 - 1 / 25), (name, axis)
+            a, b = w[:, (axis + 1) % 3], w[:, (axis + 2) % 3]
+            phi = np.arctan2(b, a)
+            hist, _ = np.histogram(phi, bins=32, range=(-np.pi, np.pi))
+            assert np.abs(hist - n / 32).max() < 5 * np.sqrt(n / 32), (name, axis)
+            for k in (1, 2):
+                assert abs(np.cos(k * phi).mean()) < sig and abs(np.sin(k * phi).mean()) < sig, (name, axis, k)
+    # isotropy between the 10-bit axis and the 11-bit ones, and lattice against continuous, axis by axis
+    assert stats.ks_2samp(v[:, 2], v[:, 0]).pvalue > 1e-4
+    assert stats.ks_2samp(v[:, 2], v[:, 1]).pvalue > 1e-4
+    for axis in range(3):
+        assert stats.ks_2samp(v[:, axis], c[:, axis]).pvalue > 1e-4, axis
+        assert stats.ks_2samp(np.abs(v[:, axis]), np.abs(v[:, (axis + 1) % 3])).pvalue > 1e-4, axis
+
+
 def test_single_vs_double_precision_tables(oracle):
     """How far the single-precision path (what the GPU computes, bit for bit) is from the double-precision
     restatement of lib.rs, pixel by pixel.  The per-pixel path signature (hash of the spheres hit, in order) tells

@@ -99,12 +99,32 @@ if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
     hbm = fetch + write
     w(f"  HBM traffic per launch             {hbm / 1e6:.1f} MB (FETCH_SIZE {pmc['FETCH_SIZE']:.0f} KiB x2 gfx950 correction + WRITE_SIZE {pmc['WRITE_SIZE']:.0f} KiB);"
       f" algorithmic bytes: {cfg['width']}*{cfg['height']}*4 B frame = {cfg['width'] * cfg['height'] * 4 / 1e6:.1f} MB + {n_pad * 68 / 1e3:.0f} KB scene")
+# What the hardware executed, beside the algorithmic count of bench.py's roofline: VALU lane-operations (an upper bound
+# of the FLOP actually done is 2 per lane-operation, as if every one were an FMA) and the share of VALU issue slots used
+# (a SIMD issues at most one wave64 fp32 instruction every 2 cycles).
+executed = None
+if pmc.get("SQ_INSTS_VALU") and pmc.get("SQ_THREAD_CYCLES_VALU") and pmc.get("GRBM_GUI_ACTIVE") and durs:
+    k_s = sum(durs) / len(durs) * 1e-3
+    cycles = pmc["GRBM_GUI_ACTIVE"] / 8
+    issue = pmc["SQ_INSTS_VALU"] / 1024 / cycles
+    executed = {"valu_wave_instructions": pmc["SQ_INSTS_VALU"], "valu_lane_operations": pmc["SQ_THREAD_CYCLES_VALU"],
+                "lane_operations_per_segment": pmc["SQ_THREAD_CYCLES_VALU"] / seg,
+                "flop_upper_bound_tflops": 2.0 * pmc["SQ_THREAD_CYCLES_VALU"] / k_s * 1e-12,
+                "flop_upper_bound_frac_of_peak": 2.0 * pmc["SQ_THREAD_CYCLES_VALU"] / k_s * 1e-12 / bench["roofline"]["peak"],
+                "valu_issue_per_simd_cycle": issue, "valu_issue_frac_of_slots": issue / 0.5,
+                "active_lane_frac": pmc["SQ_THREAD_CYCLES_VALU"] / pmc["SQ_INSTS_VALU"] / 64.0,
+                "shader_clock_ghz": cycles / k_s * 1e-9,
+                "note": "PMC passes of bench.py --steps 1 with this code object; flop_upper_bound counts every VALU lane-operation as an FMA"}
+    w(f"  executed VALU lane-operations per segment  {executed['lane_operations_per_segment']:.0f} (algorithmic count: {bench['roofline']['flop_per_segment']} FLOP);"
+      f" as if all were FMAs: {executed['flop_upper_bound_tflops']:.1f} TFLOP/s = {100 * executed['flop_upper_bound_frac_of_peak']:.1f} % of peak;"
+      f" VALU issue slots used: {100 * executed['valu_issue_frac_of_slots']:.1f} %")
 open(os.path.join(dst, f"{tag}_rocprof_summary.txt"), "w").write("\n".join(l for l in lines) + "\n")
 if hbm is not None:
     json.dump({"hbm_bytes_per_launch": hbm, "fetch_size_kib": pmc["FETCH_SIZE"], "write_size_kib": pmc["WRITE_SIZE"],
-               "code_object_sha256": sha, "workload": cfg["workload"],
+               "code_object_sha256": sha, "workload": cfg["workload"], "executed": executed,
                "note": "rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in separate passes of bench.py --steps 1; FETCH_SIZE doubled (gfx950 correction)"},
               open(os.path.join(dst, f"{tag}_hbm_traffic.json"), "w"))
 bench["roofline"]["traffic"] = hbm
+bench["roofline"]["executed"] = executed
 json.dump(bench, open(os.path.join(dst, f"{tag}_bench_1gpu.json"), "w"))
 print("\n".join(lines))

@@ -13,7 +13,7 @@ __global__ void k(const float4* __restrict__ g, float4* out, int count) {
         const int wave_first = i - (int)(threadIdx.x & 63u);
         __builtin_amdgcn_global_load_lds(g + i, (__attribute__((address_space(3))) void*)(lds + wave_first), 16, 0, 0);
     }
-    __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0) (expcnt 7, lgkmcnt 15 untouched... encoding for gfx9: vmcnt low bits)
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // gfx9 encoding: vmcnt(0) (bits 3:0 and 15:14 = 0), expcnt 7 (bits 6:4) and lgkmcnt 15 (bits 11:8) left alone
     __syncthreads();
     out[threadIdx.x] = lds[threadIdx.x];
 }
