@@ -35,6 +35,7 @@ typedef struct RtLaunch {
     float    translate[3];     // T of the scan filter: component-wise median of the sphere centres
     uint32_t fold;             // queue kernels: 1 = finished samples go to the workspace and are added in sample order (fp32 fold)
     uint32_t pool_slots;       // rt_render_pool: open units per workgroup (LDS pool)
+    float    scan_scale;       // sigma of the scan filter: a power of two, sigma * |c - o| <= 1/2 for origins on the scene's spheres
 } RtLaunch;
 
 // Launch-wide counter block of the render kernels, device memory, cleared before every launch: sixteen 64-bit

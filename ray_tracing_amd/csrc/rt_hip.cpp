@@ -44,6 +44,11 @@ struct rt_ctx {
     void *d_geom = nullptr, *d_exact = nullptr, *d_shade = nullptr, *d_mat = nullptr;
     void* d_camterms = nullptr;         // per sphere {A, B, C, sq} of the camera-ray scan, rewritten by every launch (rt_camera_terms)
     float translate[3] = {0.0f, 0.0f, 0.0f};
+    // Scale of the scan filter (rt_kernels.hip, scan_tile): sigma = 2^-k with sigma * 4 R <= 1, R = the largest
+    // |centre - translate| + radius of the scene; scene_radius = R, or a negative number when the scene has no usable
+    // bound (non-finite or absurd values): such scenes stay off the kernels whose bounce scan relies on the bound.
+    float scan_scale = 1.0f;
+    double scene_radius = 0.0;
     uint32_t n_spheres = 0, n_padded = 0;
     bool have_scene = false;
     void *d_rgba = nullptr, *d_linear = nullptr, *d_hits = nullptr, *d_counter = nullptr;
@@ -185,9 +190,21 @@ int check_render(rt_ctx* c, const RtParams* p) {
 }
 
 // can this launch run on the camera-ray-batch kernels?  (every sample its own work item)
-bool queue_kernel_fits(const rt_ctx* c, uint32_t spp) {
-    return !c->dbg_no_queue && spp >= 2u && (uint64_t)64u * spp < (1ull << 31) &&
-           c->n_padded <= 65536u;                                // a queued ray names the sphere it left in 16 bits
+bool queue_kernel_fits(const rt_ctx* c, const RtCamera* cam, uint32_t spp) {
+    if (c->dbg_no_queue || spp < 2u || (uint64_t)64u * spp >= (1ull << 31) ||
+        c->n_padded > 65536u)                                    // a queued ray names the sphere it left in 16 bits
+        return false;
+    // Their bounce scan assumes that a bounce ray starts within R (1 + small) of the scene's translation point (it
+    // starts on a sphere).  A hit point carries the rounding of o + t d, which grows with the camera's distance: a
+    // camera farther than 2^12 R away (or a scene without a bound) keeps the launch on the other kernels.
+    if (c->n_spheres == 0u) return true;
+    if (!(c->scene_radius > 0.0)) return false;
+    double dist2 = 0.0;
+    for (int k = 0; k < 3; k++) {
+        const double dk = (double)cam->center[k] - (double)c->translate[k];
+        dist2 += dk * dk;
+    }
+    return dist2 <= 4096.0 * 4096.0 * c->scene_radius * c->scene_radius;   // false for NaN
 }
 
 // fold_queue: sample_chunk = 0 (the reference's fp32 fold) may run on the camera-ray-batch kernels with a workspace
@@ -217,7 +234,7 @@ RtLaunch make_launch(const rt_ctx* c, const RtCamera* cam, const RtParams* p, ui
     // work decomposition of the render kernels
     const uint32_t spp = p->samples_per_pixel ? p->samples_per_pixel : 1u;
     const bool fold = p->sample_chunk == 0 || p->sample_chunk >= spp;
-    if (fold && !(fold_queue && queue_kernel_fits(c, spp))) {
+    if (fold && !(fold_queue && queue_kernel_fits(c, cam, spp))) {
         L.chunk = spp; L.n_chunks = 1; L.unit_w = L.unit_h = 8;         // one lane per pixel, fp32 fold
     } else {
         L.fold = fold ? 1u : 0u;                                        // samples traced in any order, added in sample order
@@ -260,7 +277,7 @@ RtLaunch make_launch(const rt_ctx* c, const RtCamera* cam, const RtParams* p, ui
         uint64_t per_wave = (uint64_t)128u * p->max_depth / 50u;
         per_wave = per_wave < 64u ? 64u : per_wave > 512u ? 512u : per_wave;
         const uint64_t pool_below = per_wave * resident;
-        const bool pool_able = L.chunk == 1u && L.n_chunks > 1u && queue_kernel_fits(c, spp) && p->max_depth > 0u &&
+        const bool pool_able = L.chunk == 1u && L.n_chunks > 1u && queue_kernel_fits(c, cam, spp) && p->max_depth > 0u &&
                                c->n_padded <= RT_TILE_SPHERES && (fold ? c->f_render_pool_fold : c->f_render_pool) != nullptr &&
                                c->dbg_scheduler != RT_SCHED_WAVE;
         grow(0u);
@@ -279,6 +296,7 @@ RtLaunch make_launch(const rt_ctx* c, const RtCamera* cam, const RtParams* p, ui
         }
     }
     for (int k = 0; k < 3; k++) L.translate[k] = c->translate[k];
+    L.scan_scale = c->scan_scale;
     for (L.unit_shift = 0; (1u << L.unit_shift) < L.unit_w; L.unit_shift++) {}
     for (L.unit_pshift = 0; (1u << L.unit_pshift) < L.unit_w * L.unit_h; L.unit_pshift++) {}
     L.units_x = (cam->image_width + L.unit_w - 1u) / L.unit_w;
@@ -311,7 +329,7 @@ int launch_render(rt_ctx* c, const RtCamera* cam, const RtParams* p, RtLaunch L,
     hipFunction_t f;
     unsigned lds;
     if ((uint64_t)P * L.n_chunks >= (1ull << 31)) return fail(c, RT_ERR_INVALID, "too many work items per pixel unit (samples_per_pixel / sample_chunk too large)");
-    const bool queue = L.n_chunks > 1 && L.chunk == 1 && queue_kernel_fits(c, L.samples_per_pixel);
+    const bool queue = L.n_chunks > 1 && L.chunk == 1 && queue_kernel_fits(c, cam, L.samples_per_pixel);
     if (L.fold && !queue) return fail(c, RT_ERR_INVALID, "internal: fold-order launch prepared for a kernel that cannot run it");
     if (queue) {
         // every sample its own item: camera rays traced in batches, bounce rays from a queue
@@ -574,6 +592,28 @@ int rt_upload_scene(rt_ctx* c, const RtSphere* spheres, uint32_t n) {
             T[k] = std::isfinite(v[n / 2]) ? v[n / 2] : 0.0f;
         }
     }
+    // R = largest |c - T| + |radius|, and the filter's scale sigma = 2^-k <= 1 / (4 R)
+    double R = 0.0;
+    for (uint32_t i = 0; i < n; i++) {
+        double cc = 0.0;
+        for (int k = 0; k < 3; k++) {
+            const double ck = (double)(float)((double)spheres[i].center[k] - (double)T[k]);
+            cc += ck * ck;
+        }
+        const double reach = std::sqrt(cc) + std::fabs((double)spheres[i].radius);
+        if (!(reach <= R)) R = reach;                             // a NaN sticks
+    }
+    float sigma = 1.0f;
+    double scene_radius = -1.0;
+    if (n == 0) {
+        scene_radius = 0.0;
+    } else if (std::isfinite(R) && R >= 0x1p-40 && R <= 0x1p40) {
+        int k = 0;
+        (void)std::frexp(4.0 * R, &k);                            // 4 R = f * 2^k, f in [0.5, 1): 2^-k * 4 R < 1
+        sigma = (float)std::ldexp(1.0, -k);
+        scene_radius = R;
+    }
+    const double s2 = (double)sigma * (double)sigma;
     std::vector<float> geom((size_t)n_padded * 4), exact((size_t)n_padded * 4), shade((size_t)n_padded * 12, 0.0f);
     std::vector<uint32_t> mat(n_padded);
     for (uint32_t i = 0; i < n_padded; i++) {
@@ -592,7 +632,7 @@ int rt_upload_scene(rt_ctx* c, const RtSphere* spheres, uint32_t n) {
                 x[k] = sp.center[k];
             }
             const double m = (double)rr * (1.0 + 0x1p-17) - cc * (1.0 - 0x1p-18);
-            g[3] = std::nextafter((float)m, INFINITY);
+            g[3] = std::nextafter((float)m, INFINITY) * (float)s2;   // times sigma^2, a power of two: exact
             x[3] = rr;
             float param = sp.param;
             if (sp.material == RT_MAT_REFLECT) param = param < 1.0f ? param : 1.0f;   // library.cu:144
@@ -633,6 +673,8 @@ int rt_upload_scene(rt_ctx* c, const RtSphere* spheres, uint32_t n) {
     RT_HIP(c, hipMemcpy(c->d_shade, shade.data(), 3 * bytes, hipMemcpyHostToDevice));
     RT_HIP(c, hipMemcpy(c->d_mat, mat.data(), (size_t)n_padded * 4u, hipMemcpyHostToDevice));
     for (int k = 0; k < 3; k++) c->translate[k] = T[k];
+    c->scan_scale = sigma;
+    c->scene_radius = scene_radius;
     c->n_spheres = n;
     c->n_padded = n_padded;
     c->have_scene = true;

@@ -253,15 +253,33 @@ RT_DEV float filter_inv_len(float a) { return __builtin_amdgcn_rsqf(a) * (1.0f +
 // become entries of the lane's candidate list.
 // (Reading the filter data with scalar loads instead -- wave-uniform global addresses, the four values of a
 // sphere as SGPR operands -- was built and measured 19 % slower than the LDS tile on the 485-sphere scene.)
-RT_DEV void scan_tile(const Tile& tile, uint32_t count, int base, V3 T,
+//
+// Scale.  The whole expression is evaluated times sigma^2, sigma a power of two chosen per scene at upload
+// (RtLaunch.scan_scale): uf and e carry sigma, w and k0 sigma^2, and the uploaded m is m sigma^2.  Scaling by a power
+// of two commutes with every rounding, so the sign of key is the same bit for bit.
+//
+// HALF = true (bounce rays of the camera-ray-batch kernels): spheres whose centre lies BEHIND the ray are dropped
+// unless the origin is inside them.  g = uf.(c - o) is the (inflated) distance along the ray to the point nearest the
+// centre; with g < 0 that point is behind the origin, and the exact test can then accept only if the origin is inside
+// the sphere: its acceptance needs h > 0 or ncc > 0 (accept_exact), and h = d.oc > 0 with g < 0 means |u.oc| is
+// below g's rounding error (8 * 2^-24 |oc|), so disc >= 0 needs |oc|^2 - r*r below 64 * 2^-48 |oc|^2 -- also "inside"
+// to within what the inflations cover.  So for g < 0 the key is t + m alone (r*r - |c-o|^2, inflated), i.e.
+// key = gc*gc + t + m with gc = max(g, 0).  The max costs nothing: sigma is chosen so that sigma |c - o| <= 1/2 for
+// every origin on a sphere of the scene (the launcher keeps cameras too far away for that off these kernels), hence
+// gc = clamp(g, 0, 1), the output modifier of the fma that produces g.  A ray leaving a sphere no longer lists that
+// sphere, nor the ground or the mirror behind it: book scene 1.85 -> candidates per ray, see DESIGN.md.
+// (NaN: the clamp turns it into 0, key = t + m decides; the exact test rejects every sphere for a NaN ray anyway.)
+template <bool HALF>
+RT_DEV void scan_tile(const Tile& tile, uint32_t count, int base, V3 T, float sigma,
                       V3 o, V3 d, float a, float t_min, Best& b, Cand& c, Stats& st) {
     st.wave(1);
     const V3 op = vsub(o, T);
-    const float inv_len = filter_inv_len(a);
+    const float inv_len = filter_inv_len(a) * sigma;
     const V3 uf = v3(d.x * inv_len, d.y * inv_len, d.z * inv_len);
     const float e = -vdot(uf, op);
-    const V3 w = v3(2.0f * op.x, 2.0f * op.y, 2.0f * op.z);
-    const float k0 = -(vdot(op, op) * (1.0f - 0x1p-18f));
+    const float s2 = sigma * sigma;
+    const V3 w = v3((2.0f * s2) * op.x, (2.0f * s2) * op.y, (2.0f * s2) * op.z);
+    const float k0 = -(vdot(op, op) * (1.0f - 0x1p-18f)) * s2;
     // 8 spheres: eight 16-byte LDS reads, then 72 operations; the sign bits are shifted into `miss`
     auto step8 = [&](const float4* p8, uint32_t& miss) {
         float4 s[RT_SCAN_UNROLL];
@@ -270,7 +288,10 @@ RT_DEV void scan_tile(const Tile& tile, uint32_t count, int base, V3 T,
 #pragma unroll
         for (uint32_t u = 0; u < RT_SCAN_UNROLL; u++) {
             const float t = fmaf(w.z, s[u].z, fmaf(w.y, s[u].y, fmaf(w.x, s[u].x, k0)));
-            const float g = fmaf(uf.z, s[u].z, fmaf(uf.y, s[u].y, fmaf(uf.x, s[u].x, e)));
+            const float g2 = fmaf(uf.y, s[u].y, fmaf(uf.x, s[u].x, e));
+            float g;
+            if (HALF) asm("v_fma_f32 %0, %1, %2, %3 clamp" : "=v"(g) : "v"(uf.z), "v"(s[u].z), "v"(g2));
+            else g = fmaf(uf.z, s[u].z, g2);
             const float key = fmaf(g, g, t) + s[u].w;
             miss = __builtin_amdgcn_alignbit(miss, __float_as_uint(key), 31u);
         }
@@ -745,10 +766,10 @@ RT_DEV void render_body(const Scene& sc, uint32_t* __restrict__ rgba, float4* __
                 if (first) __syncthreads();                      // previous tile fully scanned
                 tile = stage_tile(L, sc.geom, sc.exact, first, count);
                 __syncthreads();
-                if (active) scan_tile(tile, count, (int)first, T, o, d, a, L.t_min, b, cand, st);
+                if (active) scan_tile<false>(tile, count, (int)first, T, L.scan_scale, o, d, a, L.t_min, b, cand, st);
             }
         } else {
-            if (active) scan_tile(tile, L.n_padded, 0, T, o, d, a, L.t_min, b, cand, st);
+            if (active) scan_tile<false>(tile, L.n_padded, 0, T, L.scan_scale, o, d, a, L.t_min, b, cand, st);
         }
         bool finished = false;                                   // this lane completed its item in this round
         if (active) {
@@ -1097,7 +1118,7 @@ RT_DEV void render_queue_body(const Scene& sc, uint32_t* __restrict__ rgba, floa
             Best b;
             b.t = L.t_max;
             b.idx = -1;
-            scan_tile(tile, S, 0, T, p.o, p.d, vdot(p.d, p.d), L.t_min, b, cand, st);
+            scan_tile<true>(tile, S, 0, T, L.scan_scale, p.o, p.d, vdot(p.d, p.d), L.t_min, b, cand, st);
             nseg++;
             V3 color;
             if (shade_segment(sc, L, seed, b, pixel, s, band, p, color, st)) {
@@ -1394,7 +1415,7 @@ RT_DEV void render_pool_body(const Scene& sc, uint32_t* __restrict__ rgba, float
             Best b;
             b.t = L.t_max;
             b.idx = -1;
-            scan_tile(tile, S, 0, T, p.o, p.d, vdot(p.d, p.d), L.t_min, b, cand, st);
+            scan_tile<true>(tile, S, 0, T, L.scan_scale, p.o, p.d, vdot(p.d, p.d), L.t_min, b, cand, st);
             nseg++;
             V3 color;
             if (shade_segment(sc, L, seed, b, pixel, s, band, p, color, st)) {
@@ -1573,7 +1594,7 @@ RT_DEV void render_queue_stream_body(const Scene& sc, uint32_t* __restrict__ rgb
 #ifdef RT_EXP_PRIMARY2
                 if (primary) scan_primary(geo0, tile, count, (int)first, bfx, bfy, ro, rd, ra, L.t_min, b, cand, st);   // cost experiment
 #endif
-                else scan_tile(tile, count, (int)first, T, ro, rd, ra, L.t_min, b, cand, st);
+                else scan_tile<true>(tile, count, (int)first, T, L.scan_scale, ro, rd, ra, L.t_min, b, cand, st);
             }
         }
 
@@ -1765,7 +1786,7 @@ rt_primary_hits(const float4* geom, const float4* exact, int32_t* hits, RtCamera
         if (first) __syncthreads();
         Tile tile = stage_tile(L, geom, exact, first, count);
         __syncthreads();
-        if (valid) scan_tile(tile, count, (int)first, ld3(L.translate), o, d, a, L.t_min, b, cand, st);
+        if (valid) scan_tile<false>(tile, count, (int)first, ld3(L.translate), L.scan_scale, o, d, a, L.t_min, b, cand, st);
     }
     if (valid) hits[(size_t)ly * L.width + x] = b.idx;
 }

@@ -8,6 +8,12 @@ Kernel (rt_kernels.hip, scan_tile), with T the scene translation, c' = fl(c - T)
   key = fma(g, g, t) + m                               m = r*r(1+2^-17) - |c'|^2 (1-2^-18), rounded up;
   candidate iff sign(key) clear.
 Exact test (checker order):  disc = fma(h, h, a*ncc),  h = d.oc,  ncc = r*r - oc.oc, oc = c - o;  needs disc >= 0.
+Bounce rays of the camera-ray-batch kernels (scan_tile<true>) use  key = fma(gc, gc, t) + m  with gc = clamp(g, 0, 1):
+a sphere whose centre lies behind the ray is dropped unless the origin is inside it.  There the exact test's full
+precondition is the bar: disc >= 0 and (h > 0 or ncc > 0) (accept_exact).  The whole expression is evaluated times
+sigma^2 (uf, e times sigma; w, k0, m times sigma^2), sigma a power of two with sigma |c - o| <= 1/2 for origins on the
+scene's spheres, so that the clamp's upper end is never reached; both the scaling (bit-identical signs) and the bound
+are checked here.
 Camera rays (scan_primary) share their origin o and their directions are affine in the image coordinates,
 d = P0 + fx du + fy dv, so with q = c - o the condition becomes |d.q| / |d| >= sqrt(|q|^2 - r*r) and d.q = C + fx A + fy B:
   rt_camera_terms (double precision, once per launch and sphere): A = du.q, B = dv.q, C = P0.q,
@@ -38,25 +44,38 @@ def terms(o, d, c, rr):
     return oc, a, h, ncc, disc
 
 
-def filt(o, d, c, rr, a, T, rsq_ulp=0):
+def filt(o, d, c, rr, a, T, rsq_ulp=0, sigma=1.0, half=False):
+    """key of scan_tile<half> with the scene scale sigma (a power of two); also returns sigma * g, the clamp's input."""
+    sigma = f32(sigma)
+    s2 = (sigma * sigma).astype(f32)
     cp = [(c[k].astype(np.float64) - np.float64(T[k])).astype(f32) for k in range(3)]       # upload, in double
     cc = sum(cp[k].astype(np.float64) ** 2 for k in range(3))
     m = np.nextafter((rr.astype(np.float64) * (1.0 + 2.0 ** -17) - cc * (1.0 - 2.0 ** -18)).astype(f32), f32(np.inf))
+    m = (m * s2).astype(f32)
     op = [(o[k] - f32(T[k])).astype(f32) for k in range(3)]                                 # kernel, per ray
     rsq = (1.0 / np.sqrt(a.astype(np.float64))).astype(f32)                                 # v_rsq_f32: within 1 ulp of this
     if rsq_ulp:
         rsq = np.nextafter(rsq, f32(np.inf) if rsq_ulp > 0 else f32(0.0))
-    inv = (rsq * f32(1.0 + 2.0 ** -19)).astype(f32)
+    inv = ((rsq * f32(1.0 + 2.0 ** -19)).astype(f32) * sigma).astype(f32)
     uf = [(d[k] * inv).astype(f32) for k in range(3)]
     e = -dot(uf, op)
-    w = [(f32(2.0) * op[k]).astype(f32) for k in range(3)]
-    k0 = -((dot(op, op) * f32(1.0 - 2.0 ** -18)).astype(f32))
+    w = [((f32(2.0) * s2).astype(f32) * op[k]).astype(f32) for k in range(3)]
+    k0 = (-((dot(op, op) * f32(1.0 - 2.0 ** -18)).astype(f32)) * s2).astype(f32)
     t = fma(w[2], cp[2], fma(w[1], cp[1], fma(w[0], cp[0], k0)))
     g = fma(uf[2], cp[2], fma(uf[1], cp[1], fma(uf[0], cp[0], e)))
-    return (fma(g, g, t) + m).astype(f32)
+    gc = np.clip(g, f32(0.0), f32(1.0)) if half else g
+    return (fma(gc, gc, t) + m).astype(f32), g
 
 
-def check(o, d, c, r, label, T=(0.0, 0.0, 0.0)):
+def scene_sigma(c, r, T):
+    """The launcher's choice (rt_upload_scene): sigma = 2^-k, 2^k > 4 R, R = max |c - T| + r."""
+    R = (np.sqrt(sum((c[k].astype(np.float64) - T[k]) ** 2 for k in range(3))) + r).max()
+    return float(2.0 ** -np.frexp(4.0 * R)[1]), R
+
+
+def check(o, d, c, r, label, T=(0.0, 0.0, 0.0), bounce=False):
+    """bounce: the origins lie on (or inside) spheres of the scene {c, r}, as bounce rays' do: the half-line filter of
+    scan_tile<true> with the scene's scale is checked as well."""
     o = [x.astype(f32) for x in o]
     d = [x.astype(f32) for x in d]
     c = [x.astype(f32) for x in c]
@@ -64,11 +83,23 @@ def check(o, d, c, r, label, T=(0.0, 0.0, 0.0)):
     oc, a, h, ncc, disc = terms(o, d, c, rr)
     accepted = disc >= 0
     assert accepted.sum() > 0, label
+    sigma, R = scene_sigma(c, r, T)
     for rsq_ulp in (-1, 0, 1):
-        key = filt(o, d, c, rr, a, [f32(x) for x in T], rsq_ulp)
+        key, _ = filt(o, d, c, rr, a, [f32(x) for x in T], rsq_ulp)
         dropped = accepted & np.signbit(key)
         assert not dropped.any(), (f"{label}: {dropped.sum()} exact-test candidates dropped by the scan_tile filter "
                                    f"(1/sqrt off by {rsq_ulp} ulp)")
+        # the scene's power-of-two scale changes no sign
+        scaled, _ = filt(o, d, c, rr, a, [f32(x) for x in T], rsq_ulp, sigma=sigma)
+        assert np.array_equal(np.signbit(scaled), np.signbit(key)), label
+        if bounce:
+            needed = accepted & ((h > 0) | (ncc > 0))            # accept_exact's precondition
+            assert needed.sum() > 0, label
+            half, g = filt(o, d, c, rr, a, [f32(x) for x in T], rsq_ulp, sigma=sigma, half=True)
+            assert g.max() <= 0.5 + 1e-3, (label, float(g.max()))  # far from the clamp's upper end
+            dropped = needed & np.signbit(half)
+            assert not dropped.any(), (f"{label}: {dropped.sum()} spheres the exact test can accept dropped by the half-line filter "
+                                       f"(1/sqrt off by {rsq_ulp} ulp)")
     return accepted.mean()
 
 
@@ -124,7 +155,8 @@ def test_huge_ground_sphere_and_origins_on_surfaces():
     # origins on the surface of small spheres (bounce rays), all directions
     c = rng.uniform(-12, 12, (3, n)); r = rng.uniform(0.2, 1.0, n)
     o = c + unit(rng, n) * r * (1.0 + rng.uniform(-2e-7, 2e-7, n))
-    check(list(o), list(unit(rng, n) * rng.uniform(0.3, 2.0, n)), list(c), r, "surface origins")
+    check(list(o), list(unit(rng, n) * rng.uniform(0.3, 2.0, n)), list(c), r, "surface origins", bounce=True)
+    check(list(o), list(unit(rng, n) * rng.uniform(0.3, 2.0, n)), list(c), r, "surface origins, translated", T=(0.5, -0.25, 1.0), bounce=True)
 
 
 def test_extreme_scales():
@@ -148,9 +180,9 @@ def test_origins_inside_spheres_on_surfaces_and_far_from_the_translation():
     n = 1_000_000
     c = rng.uniform(-10, 10, (3, n)); r = rng.uniform(0.5, 30.0, n)
     o = c + unit(rng, n) * r * rng.uniform(0.0, 0.999, n)                   # inside
-    assert check(list(o), list(unit(rng, n) * rng.uniform(0.1, 4.0, n)), list(c), r, "origin inside") == 1.0
+    assert check(list(o), list(unit(rng, n) * rng.uniform(0.1, 4.0, n)), list(c), r, "origin inside", bounce=True) == 1.0
     o = c + unit(rng, n) * r                                                  # on the surface, to rounding
-    check(list(o), list(unit(rng, n)), list(c), r, "origin on a surface")
+    check(list(o), list(unit(rng, n)), list(c), r, "origin on a surface", bounce=True)
     for far in (1e3, 1e4, 1e5):
         c = rng.uniform(-20, 20, (3, n)) + far * unit(rng, 1)
         r = rng.uniform(0.05, 2.0, n)
@@ -285,3 +317,58 @@ def test_camera_ray_filter_camera_inside_on_surfaces_and_the_ground_sphere():
         r = np.full(n, 1000.0)
         c = o64 + np.stack([rng.uniform(-5, 5, n), -1000.0 - rng.uniform(1e-4, 3.0, n), rng.uniform(-5, 5, n)])
         check_camera(cam, fx, fy, list(c), r, f"{name}, ground sphere")
+
+
+def test_half_line_filter_on_bounce_rays_between_spheres():
+    """Bounce rays as the kernels see them: origins on the surface of one sphere of a scene (to rounding, inside and
+    outside), aimed at, past and away from another sphere of the same scene -- grazing it within a few ulps, hitting it
+    squarely, or with the target behind the ray; the book scene's ground and the mirror hall's r = 25 mirrors among
+    them.  The half-line filter must keep every sphere accept_exact can accept, and drops most of those behind."""
+    rng = np.random.default_rng(8)
+    n = 1_000_000
+    for name, extent, big in (("book", 12.0, (0.0, -1000.0, 0.0, 1000.0)), ("hall", 6.0, (0.0, 0.0, 30.0, 25.0)), ("plain", 20.0, None)):
+        # a scene of m spheres; pairs (origin sphere i, target sphere j) drawn from it
+        m = 400
+        sc = rng.uniform(-extent, extent, (3, m)); sr = rng.uniform(0.2, 1.0, m)
+        if big:
+            sc[:, 0] = big[:3]; sr[0] = big[3]
+        T = np.median(sc, axis=1)
+        i = rng.integers(0, m, n); j = rng.integers(0, m, n)
+        i[: n // 4] = 0 if big else i[: n // 4]                    # a quarter of the rays leave the big sphere
+        j[n // 4: n // 2] = 0 if big else j[n // 4: n // 2]        # a quarter aim at it
+        on = unit(rng, n)
+        if big:                                                    # on the big sphere: near the part the scene sits on
+            toward = (np.median(sc[:, 1:], axis=1) - sc[:, 0])
+            toward /= np.linalg.norm(toward)
+            on[:, i == 0] = (toward[:, None] + 0.02 * unit(rng, int((i == 0).sum())))
+            on /= np.linalg.norm(on, axis=0)
+        o = sc[:, i] + on * sr[i] * (1.0 + rng.uniform(-3e-7, 3e-7, n))
+        c, r = sc[:, j], sr[j]
+        oc = c - o
+        dist = np.maximum(np.linalg.norm(oc, axis=0), 1e-9)
+        wdir = oc / dist
+        perp = np.cross(wdir.T, unit(rng, n).T).T
+        perp /= np.maximum(np.linalg.norm(perp, axis=0), 1e-30)
+        kind = rng.integers(0, 4, n)
+        sin_a = np.clip(r / dist, 0.0, 1.0) * np.where(kind == 0, 1.0 + rng.uniform(-4e-7, 4e-7, n), rng.uniform(0.0, 1.3, n))
+        sin_a = np.clip(sin_a, 0.0, 1.0)
+        d = wdir * np.sqrt(1.0 - sin_a ** 2) + perp * sin_a
+        d = np.where(kind == 3, -d, d)                             # target behind the ray
+        d = np.where(kind == 2, unit(rng, n), d)                   # any direction
+        d *= rng.uniform(0.3, 3.0, n)
+        # the filter is evaluated with the whole scene's scale: pass the scene for sigma, the pairs for the test
+        o32 = [x.astype(f32) for x in o]; d32 = [x.astype(f32) for x in d]; c32 = [x.astype(f32) for x in c]
+        rr = (r.astype(f32) * r.astype(f32)).astype(f32)
+        _, a, h, ncc, disc = terms(o32, d32, c32, rr)
+        needed = (disc >= 0) & ((h > 0) | (ncc > 0))
+        sigma, R = scene_sigma([x.astype(f32) for x in sc], sr, T)
+        for rsq_ulp in (-1, 0, 1):
+            half, g = filt(o32, d32, c32, rr, a, [f32(x) for x in T], rsq_ulp, sigma=sigma, half=True)
+            assert g.max() <= 0.5 + 1e-3, (name, float(g.max()))
+            assert not (needed & np.signbit(half)).any(), (name, rsq_ulp, int((needed & np.signbit(half)).sum()))
+            full, _ = filt(o32, d32, c32, rr, a, [f32(x) for x in T], rsq_ulp, sigma=sigma)
+        listed_full, listed_half = (~np.signbit(full)).mean(), (~np.signbit(half)).mean()
+        assert needed.mean() > 0.05 and listed_half < listed_full, (name, needed.mean(), listed_half, listed_full)
+        # behind the ray and origin outside: the full-line filter lists them, the half-line filter almost none
+        behind = (kind == 3) & (i != j) & (ncc < 0)
+        assert (~np.signbit(full))[behind].mean() > 0.3 and (~np.signbit(half))[behind].mean() < 0.02, name
