@@ -10,7 +10,7 @@
 // reference's `render(rng_state, frame, Camera cam, GuiState gui)`, ray.cu:92).
 typedef struct RtLaunch {
     uint32_t n_spheres;        // spheres in the scene
-    uint32_t n_padded;         // n_spheres rounded up to RT_SCAN_UNROLL (padding never hits)
+    uint32_t n_padded;         // n_spheres rounded up to RT_SCAN_PAD (padding never hits)
     uint32_t samples_per_pixel;
     uint32_t sample2_per_pixel;
     uint32_t max_depth;
@@ -49,6 +49,8 @@ typedef struct RtLaunch {
 
 // spheres per unrolled scan step (8 measured best: 4 is 3 % slower, 16 costs a wave of occupancy and 2 %)
 #define RT_SCAN_UNROLL 8u
+// sphere lists are padded to a multiple of this (the scans end with a step of 4 and a step of 2 spheres)
+#define RT_SCAN_PAD 2u
 // Spheres staged in LDS at a time: 1024 x 32 B = 32 KiB.  Scenes up to this size are staged once per
 // workgroup; larger ones are streamed through the same buffer tile by tile.  A bigger tile means fewer
 // barriers per path segment but fewer workgroups per CU: on the 16,385-sphere scene 512 and 1024 run at

@@ -401,7 +401,7 @@ int launch_render(rt_ctx* c, const RtCamera* cam, const RtParams* p, RtLaunch L,
     if (grid > 0 && queue) {
         // the camera-ray scan's four numbers per sphere for this camera (inside the timed region: part of the frame)
         void* targs[] = {&c->d_exact, &c->d_camterms, &cam_copy, &L};
-        RT_HIP(c, hipModuleLaunchKernel(c->f_camera_terms, (c->n_padded + 255u) / 256u, 1, 1, 256, 1, 1, 0, c->stream, targs, nullptr));
+        RT_HIP(c, hipModuleLaunchKernel(c->f_camera_terms, 1, 1, 1, 1024, 1, 1, 0, c->stream, targs, nullptr));   // one workgroup: it reduces over the scene
     }
     if (grid > 0)
         RT_HIP(c, hipModuleLaunchKernel(f, grid, 1, 1, block, 1, 1, lds, c->stream, args, nullptr));
@@ -576,8 +576,11 @@ int rt_upload_scene(rt_ctx* c, const RtSphere* spheres, uint32_t n) {
     if (n && !spheres) return fail(c, RT_ERR_INVALID, "spheres is NULL");
     if (n > (1u << 24)) return fail(c, RT_ERR_INVALID, "more than 2^24 spheres");
     RT_HIP(c, hipSetDevice(c->device));
-    uint32_t n_padded = ((n + RT_SCAN_UNROLL - 1u) / RT_SCAN_UNROLL) * RT_SCAN_UNROLL;
-    if (n_padded == 0) n_padded = RT_SCAN_UNROLL;
+    // the scans take 8 spheres per step and finish with a step of 4 and one of 2: lists are padded to an even count
+    uint32_t pad = RT_SCAN_PAD;
+    if (const char* e = std::getenv("RT_EXP_SCAN_PAD")) { if (std::atoi(e) == 8) pad = 8u; }   // timing experiments only
+    uint32_t n_padded = ((n + pad - 1u) / pad) * pad;
+    if (n_padded == 0) n_padded = pad;
     // geom:  scan-filter data {c - T, m} per sphere: T = component-wise median of the centres,
     //        m = r*r(1+2^-17) - |c-T|^2 (1-2^-18), rounded up (see scan_tile in rt_kernels.hip)
     // exact: {c, r*r} per sphere for the exact test
@@ -651,7 +654,7 @@ int rt_upload_scene(rt_ctx* c, const RtSphere* spheres, uint32_t n) {
                 gt[2] = r0 * r0;
             }
         } else {
-            // padding up to the scan's unroll factor: m = -inf makes the filter value -inf, never a candidate
+            // padding: m = -inf makes the filter value -inf, never a candidate
             g[0] = g[1] = g[2] = 0.0f; g[3] = -INFINITY;
             x[0] = x[1] = x[2] = 0.0f; x[3] = -INFINITY;
             s[0] = s[1] = s[2] = 0.0f; s[3] = 1.0f;

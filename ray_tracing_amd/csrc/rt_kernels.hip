@@ -269,45 +269,53 @@ RT_DEV float filter_inv_len(float a) { return __builtin_amdgcn_rsqf(a) * (1.0f +
 // gc = clamp(g, 0, 1), the output modifier of the fma that produces g.  A ray leaving a sphere no longer lists that
 // sphere, nor the ground or the mirror behind it: book scene 1.85 -> candidates per ray, see DESIGN.md.
 // (NaN: the clamp turns it into 0, key = t + m decides; the exact test rejects every sphere for a NaN ray anyway.)
+// per-ray constants of the filter
+struct RayTerms { V3 w; float k0; V3 uf; float e; };
+
+// N spheres (8, 4 or 2): N 16-byte LDS reads, then 9 N operations; the sign bits are shifted into `miss`
+template <bool HALF, uint32_t N>
+RT_DEV void filter_step(const RayTerms& r, const float4* p, uint32_t& miss) {
+    float4 s[N];
+#pragma unroll
+    for (uint32_t u = 0; u < N; u++) s[u] = p[u];
+#pragma unroll
+    for (uint32_t u = 0; u < N; u++) {
+        const float t = fmaf(r.w.z, s[u].z, fmaf(r.w.y, s[u].y, fmaf(r.w.x, s[u].x, r.k0)));
+        const float g2 = fmaf(r.uf.y, s[u].y, fmaf(r.uf.x, s[u].x, r.e));
+        float g;
+        if (HALF) asm("v_fma_f32 %0, %1, %2, %3 clamp" : "=v"(g) : "v"(r.uf.z), "v"(s[u].z), "v"(g2));
+        else g = fmaf(r.uf.z, s[u].z, g2);
+        const float key = fmaf(g, g, t) + s[u].w;
+        miss = __builtin_amdgcn_alignbit(miss, __float_as_uint(key), 31u);
+    }
+}
+
 template <bool HALF>
 RT_DEV void scan_tile(const Tile& tile, uint32_t count, int base, V3 T, float sigma,
                       V3 o, V3 d, float a, float t_min, Best& b, Cand& c, Stats& st) {
     st.wave(1);
     const V3 op = vsub(o, T);
     const float inv_len = filter_inv_len(a) * sigma;
-    const V3 uf = v3(d.x * inv_len, d.y * inv_len, d.z * inv_len);
-    const float e = -vdot(uf, op);
     const float s2 = sigma * sigma;
-    const V3 w = v3((2.0f * s2) * op.x, (2.0f * s2) * op.y, (2.0f * s2) * op.z);
-    const float k0 = -(vdot(op, op) * (1.0f - 0x1p-18f)) * s2;
-    // 8 spheres: eight 16-byte LDS reads, then 72 operations; the sign bits are shifted into `miss`
-    auto step8 = [&](const float4* p8, uint32_t& miss) {
-        float4 s[RT_SCAN_UNROLL];
-#pragma unroll
-        for (uint32_t u = 0; u < RT_SCAN_UNROLL; u++) s[u] = p8[u];
-#pragma unroll
-        for (uint32_t u = 0; u < RT_SCAN_UNROLL; u++) {
-            const float t = fmaf(w.z, s[u].z, fmaf(w.y, s[u].y, fmaf(w.x, s[u].x, k0)));
-            const float g2 = fmaf(uf.y, s[u].y, fmaf(uf.x, s[u].x, e));
-            float g;
-            if (HALF) asm("v_fma_f32 %0, %1, %2, %3 clamp" : "=v"(g) : "v"(uf.z), "v"(s[u].z), "v"(g2));
-            else g = fmaf(uf.z, s[u].z, g2);
-            const float key = fmaf(g, g, t) + s[u].w;
-            miss = __builtin_amdgcn_alignbit(miss, __float_as_uint(key), 31u);
-        }
-    };
+    RayTerms r;
+    r.uf = v3(d.x * inv_len, d.y * inv_len, d.z * inv_len);
+    r.e = -vdot(r.uf, op);
+    r.w = v3((2.0f * s2) * op.x, (2.0f * s2) * op.y, (2.0f * s2) * op.z);
+    r.k0 = -(vdot(op, op) * (1.0f - 0x1p-18f)) * s2;
     uint32_t blk = 0u;
     for (; blk + 32u <= count; blk += 32u) {                           // full blocks: one address, constant offsets
         uint32_t miss = 0u;                                            // bit j set: sphere blk + (31-j) cannot be hit
 #pragma unroll
-        for (uint32_t i = 0; i < 32u; i += RT_SCAN_UNROLL) step8(tile.geo + blk + i, miss);
+        for (uint32_t i = 0; i < 32u; i += RT_SCAN_UNROLL) filter_step<HALF, RT_SCAN_UNROLL>(r, tile.geo + blk + i, miss);
         st.lap(9);
         decode_block(tile, base, blk, 32u, miss, o, d, a, t_min, b, c, st);
     }
-    if (blk < count) {                                                 // the last 8, 16 or 24 spheres
+    if (blk < count) {                                                 // the last 2 .. 30 spheres (count is even)
         const uint32_t k = count - blk;
-        uint32_t miss = 0u;
-        for (uint32_t i = 0; i < k; i += RT_SCAN_UNROLL) step8(tile.geo + blk + i, miss);
+        uint32_t miss = 0u, i = 0u;
+        for (; i + RT_SCAN_UNROLL <= k; i += RT_SCAN_UNROLL) filter_step<HALF, RT_SCAN_UNROLL>(r, tile.geo + blk + i, miss);
+        if (k & 4u) { filter_step<HALF, 4u>(r, tile.geo + blk + i, miss); i += 4u; }
+        if (k & 2u) filter_step<HALF, 2u>(r, tile.geo + blk + i, miss);
         st.lap(9);
         decode_block(tile, base, blk, k, miss, o, d, a, t_min, b, c, st);
     }
@@ -320,8 +328,13 @@ RT_DEV void scan_tile(const Tile& tile, uint32_t count, int base, V3 T, float si
 // condition  r*r - |q|^2 + (u.q)^2 >= 0  reads  |d.q| / |d| >= sqrt(|q|^2 - r*r),  and d.q = C + fx A + fy B with
 // three numbers per sphere, A = du.q, B = dv.q, C = P0.q.  rt_camera_terms (below) computes them once per launch, in
 // double precision, together with the right-hand side: per sphere {A, B, C, sq} in one 16-byte LDS read, and the
-// scan is  dq = fma(fx, A, fma(fy, B, C));  key = fma(|dq|, iLs, -sq)  and the sign bit: 4 operations per sphere
-// and lane (|.| is a source modifier), against 9 for a ray with an origin of its own.  Slack (so that the exact
+// scan is  dq = clamp(fma(fx, A, fma(fy, B, C)), 0, 1);  key = fma(dq, iLs, -sq)  and the sign bit: 4 operations per
+// sphere and lane (the clamp is an output modifier), against 9 for a ray with an origin of its own.  The clamp's lower
+// end drops spheres whose centre lies behind the ray (d.q < 0) unless the camera is inside them (sq = -inf below): with
+// the camera outside, the exact test accepts only if h = d.q > 0 (accept_exact), and a finite sq > 0 means that the
+// camera is outside by more than every rounding involved, s_abs included.  Its upper end is never reached: rt_camera_terms
+// multiplies A, B, C and sq by rho, a power of two with rho * M < 1/2 for every sphere (M below bounds |dq|), which
+// changes no sign.  Slack (so that the exact
 // test's  disc >= 0  implies  key >= 0):  iLs = rsq(d.d)(1 + 2^-19);  sq = sqrt(|q|^2 (1-2^-18) - r*r (1+2^-17))
 // (1 - 2^-20) - s_abs, rounded down, with the same two inflations as scan_tile for the difference between the
 // filter's condition and the exact test's own roundings, and s_abs for this form's: 4 * 2^-24 M / F for the
@@ -330,33 +343,39 @@ RT_DEV void scan_tile(const Tile& tile, uint32_t count, int base, V3 T, float si
 // in direction and in length between P0 + fx du + fy dv and make_ray's rounded d (eta: see rt_camera_terms), and
 // 2^-22 |q| for the last fma.  A camera inside the inflated sphere (or a NaN) gives sq = -inf: always a candidate;
 // padding gives sq = +inf: never.
+template <uint32_t N>
+RT_DEV void primary_step(float fx, float fy, float iLs, const float4* p, uint32_t& miss) {
+    float4 s[N];
+#pragma unroll
+    for (uint32_t u = 0; u < N; u++) s[u] = p[u];
+#pragma unroll
+    for (uint32_t u = 0; u < N; u++) {
+        const float dq1 = fmaf(fy, s[u].y, s[u].z);
+        float dq;                                                      // clamp(fx A + dq1, 0, 1): see above
+        asm("v_fma_f32 %0, %1, %2, %3 clamp" : "=v"(dq) : "v"(fx), "v"(s[u].x), "v"(dq1));
+        const float key = fmaf(dq, iLs, -s[u].w);
+        miss = __builtin_amdgcn_alignbit(miss, __float_as_uint(key), 31u);
+    }
+}
+
 RT_DEV void scan_primary(const float4* __restrict__ geo0, const Tile& tile, uint32_t count, int base,
                          float fx, float fy, V3 o, V3 d, float a, float t_min, Best& b, Cand& c, Stats& st) {
     st.wave(0);
     const float iLs = filter_inv_len(a);
-    auto step8 = [&](const float4* p8, uint32_t& miss) {
-        float4 s[RT_SCAN_UNROLL];
-#pragma unroll
-        for (uint32_t u = 0; u < RT_SCAN_UNROLL; u++) s[u] = p8[u];
-#pragma unroll
-        for (uint32_t u = 0; u < RT_SCAN_UNROLL; u++) {
-            const float dq = fmaf(fx, s[u].x, fmaf(fy, s[u].y, s[u].z));
-            const float key = fmaf(fabsf(dq), iLs, -s[u].w);
-            miss = __builtin_amdgcn_alignbit(miss, __float_as_uint(key), 31u);
-        }
-    };
     uint32_t blk = 0u;
     for (; blk + 32u <= count; blk += 32u) {
         uint32_t miss = 0u;
 #pragma unroll
-        for (uint32_t i = 0; i < 32u; i += RT_SCAN_UNROLL) step8(geo0 + blk + i, miss);
+        for (uint32_t i = 0; i < 32u; i += RT_SCAN_UNROLL) primary_step<RT_SCAN_UNROLL>(fx, fy, iLs, geo0 + blk + i, miss);
         st.lap(15);
         decode_block(tile, base, blk, 32u, miss, o, d, a, t_min, b, c, st);
     }
     if (blk < count) {
         const uint32_t k = count - blk;
-        uint32_t miss = 0u;
-        for (uint32_t i = 0; i < k; i += RT_SCAN_UNROLL) step8(geo0 + blk + i, miss);
+        uint32_t miss = 0u, i = 0u;
+        for (; i + RT_SCAN_UNROLL <= k; i += RT_SCAN_UNROLL) primary_step<RT_SCAN_UNROLL>(fx, fy, iLs, geo0 + blk + i, miss);
+        if (k & 4u) { primary_step<4u>(fx, fy, iLs, geo0 + blk + i, miss); i += 4u; }
+        if (k & 2u) primary_step<2u>(fx, fy, iLs, geo0 + blk + i, miss);
         st.lap(15);
         decode_block(tile, base, blk, k, miss, o, d, a, t_min, b, c, st);
     }
@@ -1716,23 +1735,21 @@ rt_render_stream(const float4* geom, const float4* exact, const float4* shade, c
 }
 
 // ---------------------------------------------------------------- camera-ray terms
-// Per sphere, the four numbers of scan_primary for this launch's camera: {A, B, C, sq}.  One work-item per
-// (padded) sphere, double precision; run on the launch stream before the camera-ray-batch kernels.
+// Per sphere, the four numbers of scan_primary for this launch's camera: {A, B, C, sq}, all times rho.  ONE workgroup,
+// a work-item per (padded) sphere and round, double precision; run on the launch stream before the camera-ray-batch
+// kernels.  First pass: the unscaled terms and the largest M = |C| + (W+1)|A| + (H+1)|B| of the scene; second pass: the
+// scale rho = 2^-k with rho * 2 M_max < 1 (scan_primary clamps rho * d.q to [0, 1]).  If some M is not finite, every
+// sphere becomes an unconditional candidate (sq = -inf) and nothing is scaled.
 //   exact[i] = {c, r*r} (r*r = -inf for padding)
-extern "C" __global__ void __launch_bounds__(256)
+extern "C" __global__ void __launch_bounds__(1024)
 rt_camera_terms(const float4* __restrict__ exact, float4* __restrict__ camterms, RtCamera cam, RtLaunch L) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= L.n_padded) return;
-    const float4 s = exact[i];
+    __shared__ unsigned long long m_max_bits;                    // bits of the largest M so far (M >= 0: ordered as integers; a NaN is larger than all)
+    if (threadIdx.x == 0u) m_max_bits = 0ull;
+    __syncthreads();
     const double o[3] = {cam.center[0], cam.center[1], cam.center[2]};
-    const double q[3] = {(double)s.x - o[0], (double)s.y - o[1], (double)s.z - o[2]};
     const double du[3] = {cam.pixel_delta_u[0], cam.pixel_delta_u[1], cam.pixel_delta_u[2]};
     const double dv[3] = {cam.pixel_delta_v[0], cam.pixel_delta_v[1], cam.pixel_delta_v[2]};
     const double p0[3] = {(double)cam.pixel00_loc[0] - o[0], (double)cam.pixel00_loc[1] - o[1], (double)cam.pixel00_loc[2] - o[2]};
-    const double A = du[0] * q[0] + du[1] * q[1] + du[2] * q[2];
-    const double B = dv[0] * q[0] + dv[1] * q[1] + dv[2] * q[2];
-    const double C = p0[0] * q[0] + p0[1] * q[1] + p0[2] * q[2];
-    const double qq = q[0] * q[0] + q[1] * q[1] + q[2] * q[2];
     const double W1 = (double)L.width + 1.0, H1 = (double)L.height + 1.0;   // |fx| <= W + 1, |fy| <= H + 1
     // F: distance from the camera centre to the image plane (a lower bound of |d|)
     const double n[3] = {du[1] * dv[2] - du[2] * dv[1], du[2] * dv[0] - du[0] * dv[2], du[0] * dv[1] - du[1] * dv[0]};
@@ -1747,20 +1764,49 @@ rt_camera_terms(const float4* __restrict__ exact, float4* __restrict__ camterms,
         eta += e * e;
     }
     eta = sqrt(eta);
-    const double M = fabs(C) + W1 * fabs(A) + H1 * fabs(B);
-    const double s_abs = (4.0 * 0x1p-24 * M + 2.0 * sqrt(qq) * eta) / F + 0x1p-22 * sqrt(qq);
-    const double ntm = qq * (1.0 - 0x1p-18) - (double)s.w * (1.0 + 0x1p-17);
-    float sq;
-    if (ntm > 0.0 && F > 0.0 && s_abs == s_abs && s_abs < HUGE_VAL) {
-        const double v = sqrt(ntm) * (1.0 - 0x1p-20) - s_abs;
-        sq = (float)v;
-        if ((double)sq > v || sq != sq) sq = __uint_as_float(__float_as_uint(sq) + (sq > 0.0f ? 0xffffffffu : 1u));   // round down
-        if (v <= 0.0) sq = -INFINITY;                           // nothing left of the bound: always a candidate
-    } else {
-        sq = -INFINITY;                                          // camera inside the (inflated) sphere, NaN, or no image plane
+
+    // one sphere's unscaled terms; v = the right-hand side before rounding (-inf: unconditional candidate, +inf: padding)
+    auto terms = [&](uint32_t i, double& A, double& B, double& C, double& v, double& M) {
+        const float4 s = exact[i];
+        const double q[3] = {(double)s.x - o[0], (double)s.y - o[1], (double)s.z - o[2]};
+        A = du[0] * q[0] + du[1] * q[1] + du[2] * q[2];
+        B = dv[0] * q[0] + dv[1] * q[1] + dv[2] * q[2];
+        C = p0[0] * q[0] + p0[1] * q[1] + p0[2] * q[2];
+        const double qq = q[0] * q[0] + q[1] * q[1] + q[2] * q[2];
+        M = fabs(C) + W1 * fabs(A) + H1 * fabs(B);
+        const double s_abs = (4.0 * 0x1p-24 * M + 2.0 * sqrt(qq) * eta) / F + 0x1p-22 * sqrt(qq);
+        const double ntm = qq * (1.0 - 0x1p-18) - (double)s.w * (1.0 + 0x1p-17);
+        v = -HUGE_VAL;                                           // camera inside the (inflated) sphere, NaN, or no image plane
+        if (ntm > 0.0 && F > 0.0 && s_abs == s_abs && s_abs < HUGE_VAL) {
+            v = sqrt(ntm) * (1.0 - 0x1p-20) - s_abs;
+            if (!(v > 0.0)) v = -HUGE_VAL;                       // nothing left of the bound: always a candidate
+        }
+        if (s.w == -INFINITY) { v = HUGE_VAL; A = B = C = M = 0.0; }   // padding: never a candidate
+    };
+    for (uint32_t i = threadIdx.x; i < L.n_padded; i += blockDim.x) {
+        double A, B, C, v, M;
+        terms(i, A, B, C, v, M);
+        atomicMax(&m_max_bits, (unsigned long long)__double_as_longlong(M));
     }
-    if (s.w == -INFINITY) sq = INFINITY;                         // padding: never a candidate
-    camterms[i] = make_float4((float)A, (float)B, (float)C, sq);
+    __syncthreads();
+    const double m_max = __longlong_as_double((long long)m_max_bits);
+    const bool bounded = m_max < HUGE_VAL;                       // false for inf and NaN
+    double rho = 1.0;
+    if (bounded && m_max > 0.0) {
+        int k = 0;
+        (void)frexp(2.0 * m_max, &k);                            // 2 M = f 2^k, f in [0.5, 1)
+        rho = ldexp(1.0, -k);
+    }
+    for (uint32_t i = threadIdx.x; i < L.n_padded; i += blockDim.x) {
+        double A, B, C, v, M;
+        terms(i, A, B, C, v, M);
+        if (!bounded && v != HUGE_VAL) v = -HUGE_VAL;
+        v *= rho;                                                // infinities stay
+        float sq = (float)v;
+        if (v > -HUGE_VAL && v < HUGE_VAL && ((double)sq > v || sq != sq))
+            sq = __uint_as_float(__float_as_uint(sq) + (sq > 0.0f ? 0xffffffffu : 1u));   // round down
+        camterms[i] = make_float4((float)(A * rho), (float)(B * rho), (float)(C * rho), sq);
+    }
 }
 
 // ---------------------------------------------------------------- primary-hit index map

@@ -18,7 +18,9 @@ Camera rays (scan_primary) share their origin o and their directions are affine 
 d = P0 + fx du + fy dv, so with q = c - o the condition becomes |d.q| / |d| >= sqrt(|q|^2 - r*r) and d.q = C + fx A + fy B:
   rt_camera_terms (double precision, once per launch and sphere): A = du.q, B = dv.q, C = P0.q,
       sq = sqrt(|q|^2 (1-2^-18) - r*r (1+2^-17)) (1-2^-20) - s_abs, rounded down   (s_abs: see the kernel's comment)
-  scan:  dq = fma(fx, A, fma(fy, B, C));  key = fma(|dq|, rsq(d.d)(1+2^-19), -sq);  candidate iff sign(key) clear.
+  scan:  dq = clamp(fma(fx, A, fma(fy, B, C)), 0, 1);  key = fma(dq, rsq(d.d)(1+2^-19), -sq);  candidate iff sign(key) clear,
+  with A, B, C, sq all times rho = 2^-k, rho * 2 max M < 1 (M = |C| + (W+1)|A| + (H+1)|B| bounds |dq|): the clamp's lower end
+  drops spheres behind the camera ray unless the camera is inside them; the bar is accept_exact's full precondition.
 The direction the exact test sees is make_ray's rounded one; the filter works from fx, fy.
 Here both are evaluated in numpy with float32 fma emulated through float64 (products of two float32 are
 exact in float64), on random and adversarial ray/sphere pairs."""
@@ -230,10 +232,11 @@ def camera_terms(cam, c, rr):
     ntm = qq * (1.0 - 2.0 ** -18) - rr.astype(np.float64) * (1.0 + 2.0 ** -17)
     with np.errstate(invalid="ignore"):
         v = np.sqrt(np.maximum(ntm, 0.0)) * (1.0 - 2.0 ** -20) - s_abs
+    rho = 2.0 ** -np.frexp(2.0 * M.max())[1] if np.isfinite(M.max()) and M.max() > 0 else 1.0   # the whole scene's scale
+    v = np.where((ntm > 0.0) & (v > 0.0), v, -np.inf) * rho
     sq = v.astype(f32)
-    sq = np.where(sq.astype(np.float64) > v, np.nextafter(sq, f32(-np.inf)), sq)
-    sq = np.where((ntm > 0.0) & (v > 0.0), sq, f32(-np.inf)).astype(f32)
-    return A.astype(f32), B.astype(f32), C.astype(f32), sq
+    sq = np.where(np.isfinite(v) & (sq.astype(np.float64) > v), np.nextafter(sq, f32(-np.inf)), sq).astype(f32)
+    return (A * rho).astype(f32), (B * rho).astype(f32), (C * rho).astype(f32), sq
 
 
 def check_camera(cam, fx, fy, c, r, label):
@@ -241,18 +244,19 @@ def check_camera(cam, fx, fy, c, r, label):
     c = [x.astype(f32) for x in c]
     rr = (r.astype(f32) * r.astype(f32)).astype(f32)
     o, d = camera_ray(cam, fx, fy)
-    _, a, _, _, disc = terms(o, d, c, rr)
+    _, a, h, ncc, disc = terms(o, d, c, rr)
     A, B, C, sq = camera_terms(cam, c, rr)
-    accepted = disc >= 0
+    accepted = (disc >= 0) & ((h > 0) | (ncc > 0))               # accept_exact's precondition
     assert accepted.sum() > 0, label
     dq = fma(fx, A, fma(fy, B, C))
+    assert np.abs(dq).max() <= 0.5 + 1e-3, (label, float(np.abs(dq).max()))   # far from the clamp's upper end
     for rsq_ulp in (-1, 0, 1):
         rsq = (1.0 / np.sqrt(a.astype(np.float64))).astype(f32)
         if rsq_ulp:
             rsq = np.nextafter(rsq, f32(np.inf) if rsq_ulp > 0 else f32(0.0))
         ils = (rsq * f32(1.0 + 2.0 ** -19)).astype(f32)
         with np.errstate(invalid="ignore"):
-            key = fma(np.abs(dq), ils, -sq)
+            key = fma(np.clip(dq, f32(0.0), f32(1.0)), ils, -sq)
         dropped = accepted & np.signbit(key)
         assert not dropped.any(), f"{label}: {dropped.sum()} exact-test candidates dropped by the camera-ray filter (1/sqrt off by {rsq_ulp} ulp)"
     return accepted, ~np.signbit(key)

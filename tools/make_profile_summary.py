@@ -38,7 +38,7 @@ for f in glob.glob(os.path.join(src, "pmc_*", "**", "*counter_collection.csv"), 
 seg = bench["roofline"]["segments_per_launch"]
 cfg = bench["config"]
 n_sph = cfg["spheres"]
-n_pad = (n_sph + 7) // 8 * 8
+n_pad = (n_sph + 1) // 2 * 2
 sha_file = os.path.join(src, "code_object.sha256")
 sha = open(sha_file).read().strip() if os.path.exists(sha_file) else None
 lines = []
