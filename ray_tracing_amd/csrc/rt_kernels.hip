@@ -32,7 +32,11 @@ RT_DEV V3 vscale(V3 a, float s) { return v3(a.x * s, a.y * s, a.z * s); }
 // a.x*b.x + a.y*b.y + a.z*b.z (floatN_helper.cu:109-111) as an fma chain
 RT_DEV float vdot(V3 a, V3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
 // v * (1/|v|): stands in for rnorm3df (floatN_helper.cu:120-122); cgmath's normalize (lib.rs:44,203)
+#ifdef RT_ABL_VUNIT   // ablation (changes the image): what the IEEE square root and divide of a normalisation cost
+RT_DEV V3 vunit(V3 v) { float inv = __builtin_amdgcn_rsqf(vdot(v, v)); return vscale(v, inv); }
+#else
 RT_DEV V3 vunit(V3 v) { float inv = 1.0f / sqrtf(vdot(v, v)); return vscale(v, inv); }
+#endif
 RT_DEV V3 ld3(const float* p) { return v3(p[0], p[1], p[2]); }
 
 // ---------------------------------------------------------------- diagnostics
@@ -86,6 +90,11 @@ RT_DEV uint64_t mix64(uint64_t z) {
 }
 RT_DEV Rng stream_init(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t k) {
     Rng g;
+#ifdef RT_ABL_STREAM  // ablation (changes the image): what the three 64-bit multiplies of a stream start cost
+    g.inc = ((uint64_t)pixel << 1u) | 1u;
+    g.state = (seed ^ (((uint64_t)sample << 32) | (uint64_t)k)) + g.inc;
+    return g;
+#endif
     uint64_t key = mix64(seed ^ (((uint64_t)sample << 32) | (uint64_t)k));
     g.inc = ((uint64_t)pixel << 1u) | 1u;
     g.state = g.inc + key;                       // state 0 stepped once is inc; then += initstate
@@ -127,15 +136,25 @@ struct Best { float t; int idx; };
 // h > 0 or the origin inside the sphere (ncc > 0); otherwise sqrt(disc) <= |h| and both roots are <= 0.
 RT_DEV void accept_exact(float h, float ncc, float disc, float a, float t_min, int idx, Best& b) {
     if (disc >= 0.0f && (h > 0.0f || ncc > 0.0f)) {
+#ifdef RT_ABL_EXACT   // ablation (changes the image): what the exact test's IEEE square root and divides cost
+        float s = __builtin_amdgcn_sqrtf(disc);
+        const float ia = __builtin_amdgcn_rcpf(a);
+        float root_a = (h - s) * ia;
+#else
         float s = sqrtf(disc);
         float root_a = (h - s) / a;
+#endif
         float root = root_a;
         bool ok = (t_min < root_a) && (root_a < b.t);
         // The far root is looked at only when the near one is not beyond t_min: otherwise the near one failed on the
         // upper bound, and the far one, (h + s) / a >= (h - s) / a (s >= 0, a > 0; addition and division round
         // monotonically), fails on it too -- its divide is skipped for most candidates.
         if (!(t_min < root_a)) {
+#ifdef RT_ABL_EXACT
+            float root_b = (h + s) * ia;
+#else
             float root_b = (h + s) / a;
+#endif
             root = root_b;
             ok = (t_min < root_b) && (root_b < b.t);
         }
@@ -341,8 +360,12 @@ RT_DEV void scan_tile(const Tile& tile, uint32_t count, int base, V3 T, float si
 // roundings of A, B, C and the two fma (M = |C| + (W+1)|A| + (H+1)|B| bounds every partial sum, F = the distance
 // from o to the image plane <= |d|; fx and fy are the very numbers make_ray uses), 2 |q| eta / F for the difference
 // in direction and in length between P0 + fx du + fy dv and make_ray's rounded d (eta: see rt_camera_terms), and
-// 2^-22 |q| for the last fma.  A camera inside the inflated sphere (or a NaN) gives sq = -inf: always a candidate;
-// padding gives sq = +inf: never.
+// 2^-22 |q| for the last fma.  A camera inside the sphere (or a NaN) gives sq = -inf: always a candidate; padding
+// gives sq = +inf: never.  A camera ON a sphere, or so close to it that nothing is left of the bound above, but not
+// inside it by the exact test's own single-precision ncc = r*r - |c - o|^2 <= 0 (the same number for every camera
+// ray), can still only be hit by rays with h = d.q > 0: such a sphere gets the half-space test alone, C + delta in
+// place of C and the smallest positive sq, delta bounding every rounding between the scan's dq and the exact test's h
+// -- the mirror the reflection preset's camera sits on is then listed by no camera ray instead of by all of them.
 template <uint32_t N>
 RT_DEV void primary_step(float fx, float fy, float iLs, const float4* p, uint32_t& miss) {
     float4 s[N];
@@ -401,7 +424,12 @@ RT_DEV HitInfo finish_hit(float4 cr, float t, V3 o, V3 d, uint32_t flags) {
     const float radius = cr.w;
     h.p = v3(fmaf(d.x, t, o.x), fmaf(d.y, t, o.y), fmaf(d.z, t, o.z));
     V3 pc = vsub(h.p, c);
+#ifdef RT_ABL_HITDIV  // ablation (changes the image): what the hit record's three IEEE divides cost
+    const float ir = __builtin_amdgcn_rcpf(radius);
+    V3 n = v3(pc.x * ir, pc.y * ir, pc.z * ir);
+#else
     V3 n = v3(pc.x / radius, pc.y / radius, pc.z / radius);
+#endif
     float nd = vdot(n, d);
     bool flip = (flags & RT_FLAG_FLIP_SIGNBIT) ? !(__float_as_int(nd) < 0)   // lib.rs:49-58
                                                : (nd > 0.0f);                // floatN_helper.cu:129-136
@@ -505,9 +533,14 @@ RT_DEV void sample_ray(const RtCamera& cam, const RtLaunch& L, uint64_t seed, ui
         si = (float)(s % n2) / (float)n2;
         sj = (float)(s / n2) / (float)n2;
     } else {                                                     // lib.rs:209-214
+#ifdef RT_ABL_JITTER  // ablation (changes the image): what the jitter's stream start and two outputs cost
+        si = (float)(s & 15u) * 0.0625f - 0.5f;
+        sj = (float)((s >> 4) & 15u) * 0.0625f - 0.5f;
+#else
         Rng g = stream_init(seed, pixel, s, 0u);
         si = rand01(g) - 0.5f;
         sj = rand01(g) - 0.5f;
+#endif
     }
     make_ray(cam, x, y, si, sj, o, d, fx, fy);
 }
@@ -1765,7 +1798,11 @@ rt_camera_terms(const float4* __restrict__ exact, float4* __restrict__ camterms,
     }
     eta = sqrt(eta);
 
-    // one sphere's unscaled terms; v = the right-hand side before rounding (-inf: unconditional candidate, +inf: padding)
+    // the longest camera ray direction of the frame (make_ray): |P0| + (W+1)|du| + (H+1)|dv|
+    const double d_max = sqrt(p0[0] * p0[0] + p0[1] * p0[1] + p0[2] * p0[2]) + W1 * sqrt(du[0] * du[0] + du[1] * du[1] + du[2] * du[2]) +
+                         H1 * sqrt(dv[0] * dv[0] + dv[1] * dv[1] + dv[2] * dv[2]);
+    // one sphere's unscaled terms; v = the right-hand side before rounding (-inf: unconditional candidate, +inf:
+    // padding, -1: the half-space test alone, C already shifted)
     auto terms = [&](uint32_t i, double& A, double& B, double& C, double& v, double& M) {
         const float4 s = exact[i];
         const double q[3] = {(double)s.x - o[0], (double)s.y - o[1], (double)s.z - o[2]};
@@ -1779,7 +1816,22 @@ rt_camera_terms(const float4* __restrict__ exact, float4* __restrict__ camterms,
         v = -HUGE_VAL;                                           // camera inside the (inflated) sphere, NaN, or no image plane
         if (ntm > 0.0 && F > 0.0 && s_abs == s_abs && s_abs < HUGE_VAL) {
             v = sqrt(ntm) * (1.0 - 0x1p-20) - s_abs;
-            if (!(v > 0.0)) v = -HUGE_VAL;                       // nothing left of the bound: always a candidate
+            if (!(v > 0.0)) v = -HUGE_VAL;                       // nothing left of the bound
+        }
+        if (v == -HUGE_VAL) {
+            // the exact test's own ncc for a camera ray (sphere_terms: the same single-precision operations, the same
+            // for every ray of the frame).  ncc <= 0: not inside, so a hit needs h = d.q > 0.  The scan's dq differs from
+            // the h the exact test computes by less than delta (roundings of A, B, C and the two fma: 4 * 2^-24 M; make_ray's
+            // rounded direction against P0 + fx du + fy dv: |q| eta; the exact test's own dot product: 3 * 2^-24 |d| |q|);
+            // with twice that added to C, dq <= 0 leaves no ray the exact test could accept.
+            const float ocx = s.x - cam.center[0], ocy = s.y - cam.center[1], ocz = s.z - cam.center[2];
+            const float ncc = fmaf(-ocz, ocz, fmaf(-ocy, ocy, fmaf(-ocx, ocx, s.w)));
+            const double delta = 2.0 * (4.0 * 0x1p-24 * M + sqrt(qq) * eta + 3.0 * 0x1p-24 * d_max * sqrt(qq));
+            if (ncc <= 0.0f && delta == delta && delta < HUGE_VAL) {
+                C += delta;
+                M += delta;
+                v = -1.0;
+            }
         }
         if (s.w == -INFINITY) { v = HUGE_VAL; A = B = C = M = 0.0; }   // padding: never a candidate
     };
@@ -1801,10 +1853,15 @@ rt_camera_terms(const float4* __restrict__ exact, float4* __restrict__ camterms,
         double A, B, C, v, M;
         terms(i, A, B, C, v, M);
         if (!bounded && v != HUGE_VAL) v = -HUGE_VAL;
-        v *= rho;                                                // infinities stay
-        float sq = (float)v;
-        if (v > -HUGE_VAL && v < HUGE_VAL && ((double)sq > v || sq != sq))
-            sq = __uint_as_float(__float_as_uint(sq) + (sq > 0.0f ? 0xffffffffu : 1u));   // round down
+        float sq;
+        if (v == -1.0) {
+            sq = 0x1p-126f;                                      // half-space test: candidate iff rho (dq + delta) iLs does not vanish
+        } else {
+            v *= rho;                                            // infinities stay
+            sq = (float)v;
+            if (v > -HUGE_VAL && v < HUGE_VAL && ((double)sq > v || sq != sq))
+                sq = __uint_as_float(__float_as_uint(sq) + (sq > 0.0f ? 0xffffffffu : 1u));   // round down
+        }
         camterms[i] = make_float4((float)(A * rho), (float)(B * rho), (float)(C * rho), sq);
     }
 }
