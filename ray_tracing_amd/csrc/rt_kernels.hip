@@ -1602,63 +1602,62 @@ RT_DEV void render_queue_stream_body(const Scene& sc, uint32_t* __restrict__ rgb
         const bool more = active || q_head < q_count || !drained || next_samp < n_samp || u0.open || u1.open;
         if (!__syncthreads_or(more ? 1 : 0)) break;
 
-        // this round's ray per lane: a camera ray of the batch, or the lane's bounce ray
+        // This round: the wavefront's next 64 camera rays, or one segment of its lanes' bounce rays.  The two are
+        // separate sweeps over the tiles (the choice is wave-uniform), so that a camera sweep keeps only what it needs
+        // beside the lanes' held bounce paths: the camera centre is the same for every lane, and a lane's pixel, sample
+        // number and column band are recomputed after the sweep.
         const Slot& u = cur ? u1 : u0;
-        uint32_t bpix = 0u, bs = 0u, bpixel = 0u;
-        float bband = 0.0f;
-        bool bdone = false, traced = false;
-        Path bp;
-        bp.o = bp.d = v3(0.0f, 0.0f, 0.0f); bp.thr = v3(1.0f, 1.0f, 1.0f); bp.seg = 0u; bp.nb = 0u;
-        float bfx = 0.0f, bfy = 0.0f;                            // image coordinates of the camera ray
-        if (primary) {
-            const uint32_t sidx = next_samp + lane;
-            bpix = sidx & (P - 1u);
-            bs = sidx >> L.unit_pshift;
-            const uint32_t dx = bpix & (L.unit_w - 1u), dy = bpix >> L.unit_shift;
-            const uint32_t x = u.x0 + dx, ly = u.ly0 + dy, y = u.y0 + dy;
-            const bool in_unit = sidx < n_samp;
-            traced = in_unit && x < L.width && ly < L.rows_local && y < L.height;
-            bdone = in_unit && !traced;
-            if (traced) {
-                bpixel = y * L.width + x;
-                if (flags & RT_FLAG_BAND_ALBEDO) bband = band_of(L, x);
-                sample_ray(cam, L, seed, x, y, bpixel, bs, bp.o, bp.d, bfx, bfy);
-            }
-        }
-        const bool scanning = primary ? traced : active;
-        const V3 ro = primary ? bp.o : p.o, rd = primary ? bp.d : p.d;
-        const float ra = vdot(rd, rd);
         Best b;
         b.t = L.t_max;
         b.idx = -1;
-        for (uint32_t first = 0u; first < L.n_padded; first += RT_Q_STREAM_TILE) {
-            uint32_t count = L.n_padded - first;
-            if (count > RT_Q_STREAM_TILE) count = RT_Q_STREAM_TILE;
-            if (first) __syncthreads();                          // previous tile fully scanned
-            for (uint32_t i = threadIdx.x; i < count; i += blockDim.x) {
-                geo[i] = sc.geom[first + i];
-                geo0[i] = camterms[first + i];
-            }
-            __syncthreads();
-            const Tile tile = {geo, sc.exact + first};           // exact-test data from global memory
-            if (scanning) {
-                if (primary) scan_primary(geo0, tile, count, (int)first, bfx, bfy, ro, rd, ra, L.t_min, b, cand, st);
-#ifdef RT_EXP_PRIMARY2
-                if (primary) scan_primary(geo0, tile, count, (int)first, bfx, bfy, ro, rd, ra, L.t_min, b, cand, st);   // cost experiment
-#endif
-                else scan_tile<true>(tile, count, (int)first, T, L.scan_scale, ro, rd, ra, L.t_min, b, cand, st);
-            }
-        }
-
         bool finished = false;                                   // a bounce path of this lane ended in this round
         if (primary) {
-            bool cont = false;
+            const uint32_t sidx = next_samp + lane;
+            bool traced;
+            V3 bd = v3(0.0f, 0.0f, 0.0f);
+            float bfx = 0.0f, bfy = 0.0f;                        // image coordinates of the camera ray
+            {
+                const uint32_t bpix = sidx & (P - 1u), bs = sidx >> L.unit_pshift;
+                const uint32_t dx = bpix & (L.unit_w - 1u), dy = bpix >> L.unit_shift;
+                const uint32_t x = u.x0 + dx, ly = u.ly0 + dy, y = u.y0 + dy;
+                traced = sidx < n_samp && x < L.width && ly < L.rows_local && y < L.height;
+                if (traced) {
+                    V3 o_unused;
+                    sample_ray(cam, L, seed, x, y, y * L.width + x, bs, o_unused, bd, bfx, bfy);
+                }
+            }
+            const V3 co = ld3(cam.center);                       // make_ray's origin
+            const float ba = vdot(bd, bd);
+            for (uint32_t first = 0u; first < L.n_padded; first += RT_Q_STREAM_TILE) {
+                uint32_t count = L.n_padded - first;
+                if (count > RT_Q_STREAM_TILE) count = RT_Q_STREAM_TILE;
+                if (first) __syncthreads();                      // previous tile fully scanned
+                for (uint32_t i = threadIdx.x; i < count; i += blockDim.x) {
+                    geo[i] = sc.geom[first + i];
+                    geo0[i] = camterms[first + i];
+                }
+                __syncthreads();
+                const Tile tile = {geo, sc.exact + first};       // exact-test data from global memory
+                if (traced) {
+                    scan_primary(geo0, tile, count, (int)first, bfx, bfy, co, bd, ba, L.t_min, b, cand, st);
+#ifdef RT_EXP_PRIMARY2
+                    scan_primary(geo0, tile, count, (int)first, bfx, bfy, co, bd, ba, L.t_min, b, cand, st);   // cost experiment
+#endif
+                }
+            }
+            const uint32_t bpix = sidx & (P - 1u), bs = sidx >> L.unit_pshift;
+            bool cont = false, bdone = sidx < n_samp && !traced;
             uint32_t sphere = 0u;
+            Path bp;
+            bp.o = co; bp.d = bd; bp.thr = v3(1.0f, 1.0f, 1.0f); bp.seg = 0u; bp.nb = 0u;
             if (traced) {
+                const uint32_t dx = bpix & (L.unit_w - 1u), dy = bpix >> L.unit_shift;
+                const uint32_t x = u.x0 + dx, y = u.y0 + dy;
+                const float bband = (flags & RT_FLAG_BAND_ALBEDO) ? band_of(L, x) : 0.0f;
                 nseg++;
                 sphere = (uint32_t)b.idx;
                 V3 color;
-                if (shade_segment(sc, L, seed, b, bpixel, bs, bband, bp, color, st)) {
+                if (shade_segment(sc, L, seed, b, y * L.width + x, bs, bband, bp, color, st)) {
                     add_sample(accum, P, 3u * bpix + (cur ? 3u * P : 0u), bs, L.samples_per_pixel, color, fold);
                     bdone = true;
                 } else {
@@ -1670,14 +1669,29 @@ RT_DEV void render_queue_stream_body(const Scene& sc, uint32_t* __restrict__ rgb
             const uint32_t completed = (uint32_t)__popcll(__ballot(bdone));
             if (cur) u1.left -= completed; else u0.left -= completed;
             next_samp = next_samp + 64u < n_samp ? next_samp + 64u : n_samp;
-        } else if (active) {
-            nseg++;
-            V3 color;
-            if (shade_segment(sc, L, seed, b, pixel, s, band, p, color, st)) {
-                add_sample(accum, P, pixslot, s, L.samples_per_pixel, color, fold);
-                active = false;
-                need = true;
-                finished = true;
+        } else {
+            const float ra = vdot(p.d, p.d);
+            for (uint32_t first = 0u; first < L.n_padded; first += RT_Q_STREAM_TILE) {
+                uint32_t count = L.n_padded - first;
+                if (count > RT_Q_STREAM_TILE) count = RT_Q_STREAM_TILE;
+                if (first) __syncthreads();                      // previous tile fully scanned
+                for (uint32_t i = threadIdx.x; i < count; i += blockDim.x) {
+                    geo[i] = sc.geom[first + i];
+                    geo0[i] = camterms[first + i];
+                }
+                __syncthreads();
+                const Tile tile = {geo, sc.exact + first};       // exact-test data from global memory
+                if (active) scan_tile<true>(tile, count, (int)first, T, L.scan_scale, p.o, p.d, ra, L.t_min, b, cand, st);
+            }
+            if (active) {
+                nseg++;
+                V3 color;
+                if (shade_segment(sc, L, seed, b, pixel, s, band, p, color, st)) {
+                    add_sample(accum, P, pixslot, s, L.samples_per_pixel, color, fold);
+                    active = false;
+                    need = true;
+                    finished = true;
+                }
             }
         }
         const unsigned long long fin = __ballot(finished);
