@@ -283,6 +283,15 @@ RtLaunch make_launch(const rt_ctx* c, const RtCamera* cam, const RtParams* p, ui
         grow(0u);
         if (pool_able && (n_units_with(L.unit_w, L.unit_h) < pool_below || c->dbg_scheduler == RT_SCHED_POOL)) L.pool_slots = 1u;
         else grow(80u * resident);
+        // Sphere lists streamed through LDS: a pass over the whole list takes the better part of a millisecond, a unit
+        // of 512 samples some 25 of them, and the wavefronts of a launch finish a unit apart.  With fewer than 10 such
+        // units per resident wavefront (20 per compute unit on that kernel) the units are halved once: measured on the
+        // 16,385-sphere frame at 64 spp, an eighth of the frame (6 units of 8x1 per wavefront) 179 -> 172 ms and a
+        // sixteenth 107 -> 97 ms with 4x1 units, a quarter (13 per wavefront) 323 -> 326 ms, half 617 -> 629 ms.
+        if (c->n_padded > RT_TILE_SPHERES && L.pool_slots == 0u && L.chunk == 1u && L.n_chunks > 1u && L.unit_w >= 8u &&
+            (uint64_t)L.unit_w * L.unit_h * spp >= 512u &&
+            n_units_with(L.unit_w, L.unit_h) < (uint64_t)10u * (uint64_t)(c->compute_units > 0 ? c->compute_units : 256) * 20u)
+            L.unit_w /= 2u;
         if (c->dbg_unit_w && height_ok(c->dbg_unit_h)) {                                                        // rt_debug_schedule
             L.unit_w = c->dbg_unit_w; L.unit_h = c->dbg_unit_h;
             if (pool_able && c->dbg_scheduler == RT_SCHED_AUTO) L.pool_slots = n_units_with(L.unit_w, L.unit_h) < pool_below ? 1u : 0u;
