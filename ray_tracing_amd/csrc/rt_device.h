@@ -35,6 +35,7 @@ typedef struct RtLaunch {
     float    translate[3];     // T of the scan filter: component-wise median of the sphere centres
     uint32_t fold;             // queue kernels: 1 = finished samples go to the workspace and are added in sample order (fp32 fold)
     uint32_t pool_slots;       // rt_render_pool: open units per workgroup (LDS pool)
+    uint32_t units_bottom_up;  // 1: the wavefronts take the launch's pixel units from the last row upwards
     float    scan_scale;       // sigma of the scan filter: a power of two, sigma * |c - o| <= 1/2 for origins on the scene's spheres
 } RtLaunch;
 

@@ -306,6 +306,8 @@ RtLaunch make_launch(const rt_ctx* c, const RtCamera* cam, const RtParams* p, ui
     }
     for (int k = 0; k < 3; k++) L.translate[k] = c->translate[k];
     L.scan_scale = c->scan_scale;
+    L.units_bottom_up = 0u;
+    if (const char* e = std::getenv("RT_EXP_UNITS_BOTTOM_UP")) L.units_bottom_up = std::atoi(e) ? 1u : 0u;   // timing experiments only
     for (L.unit_shift = 0; (1u << L.unit_shift) < L.unit_w; L.unit_shift++) {}
     for (L.unit_pshift = 0; (1u << L.unit_pshift) < L.unit_w * L.unit_h; L.unit_pshift++) {}
     L.units_x = (cam->image_width + L.unit_w - 1u) / L.unit_w;

@@ -649,6 +649,7 @@ struct Slot {
 
 RT_DEV Slot open_unit(const RtLaunch& L, uint32_t unit, uint32_t n_items) {
     Slot u;
+    if (L.units_bottom_up) unit = L.n_units - 1u - unit;         // the launch's last rows are handed out first
     const uint32_t ux = unit % L.units_x, uy = unit / L.units_x;
     u.x0 = ux * L.unit_w;
     u.ly0 = uy * L.unit_h;
