@@ -302,10 +302,8 @@ RT_DEV void filter_step(const RayTerms& r, const float4* p, uint32_t& miss) {
 #pragma unroll
     for (uint32_t u = 0; u < N; u++) {
         const float t = fmaf(r.w.z, s[u].z, fmaf(r.w.y, s[u].y, fmaf(r.w.x, s[u].x, r.k0)));
-        const float g2 = fmaf(r.uf.y, s[u].y, fmaf(r.uf.x, s[u].x, r.e));
-        float g;
-        if (HALF) asm("v_fma_f32 %0, %1, %2, %3 clamp" : "=v"(g) : "v"(r.uf.z), "v"(s[u].z), "v"(g2));
-        else g = fmaf(r.uf.z, s[u].z, g2);
+        float g = fmaf(r.uf.z, s[u].z, fmaf(r.uf.y, s[u].y, fmaf(r.uf.x, s[u].x, r.e)));
+        if (HALF) g = __builtin_amdgcn_fmed3f(g, 0.0f, 1.0f);      // folded into the fma's clamp output modifier
         const float key = fmaf(g, g, t) + s[u].w;
         miss = __builtin_amdgcn_alignbit(miss, __float_as_uint(key), 31u);
     }
@@ -375,9 +373,8 @@ RT_DEV void primary_step(float fx, float fy, float iLs, const float4* p, uint32_
     for (uint32_t u = 0; u < N; u++) s[u] = p[u];
 #pragma unroll
     for (uint32_t u = 0; u < N; u++) {
-        const float dq1 = fmaf(fy, s[u].y, s[u].z);
-        float dq;                                                      // clamp(fx A + dq1, 0, 1): see above
-        asm("v_fma_f32 %0, %1, %2, %3 clamp" : "=v"(dq) : "v"(fx), "v"(s[u].x), "v"(dq1));
+        // clamp(fx A + fy B + C, 0, 1): the median of three folds into the fma's clamp output modifier
+        const float dq = __builtin_amdgcn_fmed3f(fmaf(fx, s[u].x, fmaf(fy, s[u].y, s[u].z)), 0.0f, 1.0f);
         const float key = fmaf(dq, iLs, -s[u].w);
         miss = __builtin_amdgcn_alignbit(miss, __float_as_uint(key), 31u);
     }
