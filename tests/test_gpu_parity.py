@@ -391,6 +391,39 @@ def test_camera_ray_scan_with_hostile_cameras(oracle, rt, hip):
         assert np.array_equal(hits, ref), name
 
 
+def test_scenes_without_a_usable_bound_stay_off_the_batch_kernels(oracle, rt, hip):
+    """The bounce scan of the camera-ray-batch kernels drops spheres behind a ray with a clamp that relies on a bound of
+    the scene (every bounce origin within R of the scene's translation point, scaled so that sigma |c - o| <= 1/2).
+    Scenes without such a bound -- a sphere 1e30 away, an infinite radius -- and cameras farther than 2^12 R from the
+    scene keep sample_chunk = 1 on the work-item kernel; a camera 1000 R away (inside the limit) still runs the batch
+    kernels.  All bit for bit against the checker."""
+    base = rt.scene_gpu_default()
+    p = rt.DeviceGUI(samples_per_pixel=6, max_depth=8, seed=4, sample_chunk=1)
+    cam = rt.Camera.new(16.0 / 9.0, 96)
+    far = base.copy()
+    far[4]["center"] = (1.0e30, 0.0, 0.0)
+    check_render(oracle, hip, cam, far, p, as_scheduled=True)
+    assert hip.last_kernel_name() == "rt_render"
+    huge = base.copy()
+    huge[4]["radius"] = np.inf
+    hip.upload_scene(huge)
+    hip.render(cam, p)                                           # the checker's own handling of an infinite radius is not pinned: only "no fault, right kernel"
+    assert hip.last_kernel_name() == "rt_render"
+    # scene radius R ~ 120 (the r = 100 ground sphere and the mirrors at z = -50, -110)
+    near = rt.Camera.look_at(16.0 / 9.0, 96, 2.0, (0.0, 3.0e4, 1.0e5), (0.0, 0.0, -40.0))     # ~1000 R away
+    check_render(oracle, hip, near, base, p)
+    assert hip.last_kernel_name() == "rt_render_pool"
+    away = rt.Camera.look_at(16.0 / 9.0, 96, 0.02, (0.0, 3.0e5, 1.0e6), (0.0, 0.0, -40.0))    # ~9000 R away
+    check_render(oracle, hip, away, base, p, as_scheduled=True)
+    assert hip.last_kernel_name() == "rt_render"
+    # the fold (sample_chunk = 0) follows the same rule
+    check_render(oracle, hip, away, base, rt.DeviceGUI(samples_per_pixel=6, max_depth=8, seed=4, sample_chunk=0), as_scheduled=True)
+    assert hip.last_kernel_name() == "rt_render"
+    hip.upload_scene(base)
+    hip.render(cam, p)
+    assert hip.last_kernel_name() == "rt_render_pool"
+
+
 def test_randomised_scenes_all_modes(oracle, rt, hip):
     """Seeded random scenes (overlapping spheres, tiny and huge radii, all three materials, cameras inside and
     outside the cloud), random frame sizes, samplers, depths, block sizes and accumulation modes
