@@ -112,3 +112,24 @@ def test_sharded_frame_with_two_and_three_ranks_on_one_gpu(tmp_path):
     res = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, (res.stdout[-2000:], res.stderr[-4000:])
     assert "sharded threads ok" in res.stdout
+
+
+def test_command_line_renderer_with_three_ranks_on_one_gpu(tmp_path):
+    """tools/rt_render.cpp --gpus 3 --devices 0,0,0: the C++ host mirror (include/rt_host.hpp) drives
+    rt_comm_init / rt_render_frame_sharded from one std::thread per rank, all on GPU 0 through the stand-in transport;
+    the PPM it writes is byte for byte the one the single-GPU run writes."""
+    import ray_tracing_amd as rt
+    exe = os.path.join(os.path.dirname(rt.__file__), "csrc", "rt_render")
+    common = ["--scene", "book1", "--width", "200", "--spp", "6", "--depth", "20", "--seed", "12", "--chunk", "1"]
+    one, three = tmp_path / "one.ppm", tmp_path / "three.ppm"
+    res = subprocess.run([exe] + common + ["--out", str(one)], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stderr
+    env = dict(os.environ, RT_RCCL_LIB=FAKE)
+    res = subprocess.run([exe] + common + ["--gpus", "3", "--devices", "0,0,0", "--frames", "2", "--out", str(three)],
+                         capture_output=True, text=True, timeout=240, env=env)
+    assert res.returncode == 0, (res.stdout, res.stderr)
+    assert "on 3 GPUs" in res.stdout
+    assert open(one, "rb").read() == open(three, "rb").read()
+    res = subprocess.run([exe] + common + ["--gpus", "2", "--devices", "0,7", "--out", str(three)],
+                         capture_output=True, text=True, timeout=120, env=env)
+    assert res.returncode == 2 and "GPU 7" in res.stderr

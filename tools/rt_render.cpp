@@ -2,9 +2,11 @@
 // It is the headless counterpart of the reference's two window apps (cpu-implementation/src/main.rs,
 // gpu-implementation/src/main.rs): same scenes, cameras and defaults, no window.
 //   rt_render --scene cpu|gpu|book1|grid|hall [--width W] [--spp N | --grid n] [--depth D] [--seed S]
-//             [--chunk C] [--out image.ppm] [--p3f linear.ppm] [--gpus N] [--frames K]
-// --gpus N (> 1): one host thread and one context per GPU; the frame is dealt out as interleaved 8-row tiles and
-// gathered to GPU 0 with RCCL (rt_render_frame_sharded).  --frames K renders the frame K times and reports the last.
+//             [--chunk C] [--out image.ppm] [--p3f linear.ppm] [--gpus N [--devices d0,d1,...]] [--frames K]
+// --gpus N (> 1): one host thread and one context per rank; the frame is dealt out as interleaved 8-row tiles and
+// gathered to rank 0 with RCCL (rt_render_frame_sharded).  Rank r runs on GPU r, or on the r-th entry of --devices;
+// several ranks can share a GPU only with a transport that allows it (RCCL does not; the stand-in the tests load
+// through RT_RCCL_LIB does).  --frames K renders the frame K times and reports the last.
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -57,10 +59,24 @@ int main(int argc, char** argv) {
         if (gpus > 1) {
             if (!p3f.empty()) { std::fprintf(stderr, "--p3f needs --gpus 1\n"); return 2; }
             int have = 0;
-            if (rt_device_count(&have) != 0 || (uint32_t)have < gpus) {      // a missing rank would leave the others waiting in RCCL
-                std::fprintf(stderr, "rt_render: --gpus %u but %d GPU(s) are visible\n", gpus, have);
-                return 2;
+            std::vector<int> device(gpus);
+            for (uint32_t r = 0; r < gpus; r++) device[r] = (int)r;
+            const std::string list = arg(argc, argv, "--devices", "");
+            if (!list.empty()) {
+                size_t at = 0;
+                for (uint32_t r = 0; r < gpus; r++) {
+                    if (at >= list.size()) { std::fprintf(stderr, "--devices needs %u entries\n", gpus); return 2; }
+                    device[r] = std::atoi(list.c_str() + at);
+                    at = list.find(',', at);
+                    at = at == std::string::npos ? list.size() : at + 1;
+                }
             }
+            if (rt_device_count(&have) != 0) { std::fprintf(stderr, "rt_render: %s\n", rt_last_error(nullptr)); return 2; }
+            for (uint32_t r = 0; r < gpus; r++)
+                if (device[r] < 0 || device[r] >= have) {                    // a missing rank would leave the others waiting in RCCL
+                    std::fprintf(stderr, "rt_render: rank %u wants GPU %d but %d GPU(s) are visible\n", r, device[r], have);
+                    return 2;
+                }
             const std::vector<uint8_t> id = rt::HipWorld::comm_id();
             std::vector<uint64_t> rays(gpus, 0);
             std::vector<float> kernel_ms(gpus, 0.0f);
@@ -69,7 +85,7 @@ int main(int argc, char** argv) {
             // every context (GPU set-up, scene upload) exists before any rank enters the collective comm_init: a GPU
             // that cannot be set up ends the program here instead of leaving the other ranks waiting for it
             std::vector<std::unique_ptr<rt::HipWorld>> ctx;
-            for (uint32_t r = 0; r < gpus; r++) ctx.push_back(std::make_unique<rt::HipWorld>((int)r, world));
+            for (uint32_t r = 0; r < gpus; r++) ctx.push_back(std::make_unique<rt::HipWorld>(device[r], world));
             std::vector<std::thread> ranks;
             for (uint32_t r = 0; r < gpus; r++)
                 ranks.emplace_back([&, r] {
