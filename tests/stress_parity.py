@@ -3,12 +3,12 @@ filters (spheres behind rays, nested and overlapping spheres so that bounce rays
 inside glass, a huge ground, radii over four decades, scenes far from the origin, lists beyond one LDS tile), every
 sample its own work item under both schedulers plus the fold, each compared bit for bit (linear radiance, RGBA8,
 segment count) with the CPU checker (oracle/, test infrastructure).
-    python tools/stress_parity.py [N=200] [first_seed=0]
+    python tests/stress_parity.py [N=200] [first_seed=0]
 Prints one line per mismatch and a summary; exit code 1 if anything differed."""
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))   # the repository root
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
