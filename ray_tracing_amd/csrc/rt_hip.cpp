@@ -263,25 +263,28 @@ RtLaunch make_launch(const rt_ctx* c, const RtCamera* cam, const RtParams* p, ui
                 const uint64_t items = (uint64_t)L.unit_w * L.unit_h * L.n_chunks, samples = (uint64_t)L.unit_w * L.unit_h * spp;
                 uint32_t w = L.unit_w, h = L.unit_h;
                 if (w < 16u || !height_ok(2u * h)) w *= 2u; else h *= 2u;
-                if (items >= 512u && (samples >= 2048u || n_units_with(w, h) < min_units)) break;
+                // (a unit is written as one row segment per row: 16 pixels make it a whole 64-byte line, so a unit that
+                // is large enough still widens to 16 while the launch keeps its units; measured equal in time at every
+                // launch size, and the frame then reaches memory once instead of twice)
+                if (items >= 512u && ((samples >= 2048u && L.unit_w >= 16u) || n_units_with(w, h) < min_units)) break;
                 L.unit_w = w; L.unit_h = h;
             }
         };
-        // Launches that are small even in units of 2,048 samples run with the units pooled per workgroup (rt_render_pool,
-        // see launch_render), where the end of the launch costs little and the units can have their full size: 1080p
-        // book scene at 128 spp, pooled, 64 ms with 8x1 or 16x1 units, 72 ms with 4x1.  Small: fewer than 128 units per
-        // resident wavefront at max_depth 50, in proportion for other depths (between 64 and 512) -- the end of a launch
-        // lasts as long as its longest paths.  Measured: book scene (depth 50), half of the 4K frame = 84 units per
-        // wavefront equal either way, the whole = 169 0.7 % slower pooled; mirror hall (depth 100), a quarter of the 8K
-        // frame = 169 units per wavefront 1 % faster pooled, an eighth 9 %, half = 337 2 % slower.
-        uint64_t per_wave = (uint64_t)128u * p->max_depth / 50u;
-        per_wave = per_wave < 64u ? 64u : per_wave > 512u ? 512u : per_wave;
-        const uint64_t pool_below = per_wave * resident;
+        // Launches of fewer than 2^20 samples per resident wavefront (24 per compute unit) run with the units pooled per
+        // workgroup (rt_render_pool, see launch_render), where the end of the launch costs little and the units can have
+        // their full size.  Measured with 16x1 units (kernel ms, per-wavefront / pooled): book scene 4K at 500 spp, depth
+        // 50: whole frame = 675 k samples per wavefront 900 / 897, half 454 / 451, an eighth 118 / 114, a sixteenth
+        // 62 / 58; mirror hall 8K at 256 spp, depth 100: whole frame = 1.38 M samples per wavefront 373 / 379, half =
+        // 691 k 194 / 190, a quarter 105 / 96, an eighth 53 / 49.  Only launches as large as the whole hall frame are
+        // faster with the wavefronts holding their own units (the pool's 22 instructions per batch and trip weigh most
+        // where trips are short).
+        const uint64_t launch_samples = (uint64_t)cam->image_width * rows_local * spp;
+        const bool small_launch = launch_samples < ((uint64_t)resident << 20);
         const bool pool_able = L.chunk == 1u && L.n_chunks > 1u && queue_kernel_fits(c, cam, spp) && p->max_depth > 0u &&
                                c->n_padded <= RT_TILE_SPHERES && (fold ? c->f_render_pool_fold : c->f_render_pool) != nullptr &&
                                c->dbg_scheduler != RT_SCHED_WAVE;
         grow(0u);
-        if (pool_able && (n_units_with(L.unit_w, L.unit_h) < pool_below || c->dbg_scheduler == RT_SCHED_POOL)) L.pool_slots = 1u;
+        if (pool_able && (small_launch || c->dbg_scheduler == RT_SCHED_POOL)) L.pool_slots = 1u;
         else grow(80u * resident);
         // Sphere lists streamed through LDS: a pass over the whole list takes the better part of a millisecond, a unit
         // of 512 samples some 25 of them, and the wavefronts of a launch finish a unit apart.  With fewer than 10 such
@@ -294,7 +297,7 @@ RtLaunch make_launch(const rt_ctx* c, const RtCamera* cam, const RtParams* p, ui
             L.unit_w /= 2u;
         if (c->dbg_unit_w && height_ok(c->dbg_unit_h)) {                                                        // rt_debug_schedule
             L.unit_w = c->dbg_unit_w; L.unit_h = c->dbg_unit_h;
-            if (pool_able && c->dbg_scheduler == RT_SCHED_AUTO) L.pool_slots = n_units_with(L.unit_w, L.unit_h) < pool_below ? 1u : 0u;
+            if (pool_able && c->dbg_scheduler == RT_SCHED_AUTO) L.pool_slots = small_launch ? 1u : 0u;
         }
         // fold-order workspace: 2 units x P pixels x spp colours of 16 bytes per wavefront, at most 32 wavefronts per
         // compute unit resident; beyond the context's limit (8 GiB unless changed) the fold stays on the
@@ -362,12 +365,9 @@ int launch_render(rt_ctx* c, const RtCamera* cam, const RtParams* p, RtLaunch L,
         lds = (one_tile ? c->n_padded : RT_Q_STREAM_TILE) * 32u + waves * (RT_Q_CAND_CAP * 128u + 48u * P + RT_Q_WORDS * 256u);
         // Who holds the open pixel units: each wavefront two of its own (rt_render_queue), or the workgroup a pool of
         // them from which all its wavefronts take camera rays (rt_render_pool).  The pool costs about 22 more
-        // instructions per batch and trip (4K book scene, 500 spp: 0.7 % slower; 8K mirror hall: 3.5 %), but no wavefront
-        // waits for its own units' last paths and the launch's last units are finished by whole workgroups: measured on
-        // the book scene it wins from a quarter of the 4K frame down (1/8: 3 %, 1/16: 12 %; 1080p at 128 spp: 23 % with
-        // full-size units); on the mirror hall, whose paths run to 100 segments, an eighth of the 8K frame (84 units per
-        // resident wavefront) is 9 % faster pooled, a quarter 1 %, a half 2 % slower.  Hence: the pool for launches with few
-        // full-size units per resident wavefront, decided with the unit shape in make_launch.
+        // instructions per batch and trip (level on the 4K book frame, 3 % slower on the 8K mirror hall), but no wavefront
+        // waits for its own units' last paths and the launch's last units are finished by whole workgroups: it wins on
+        // small launches (an eighth of the book frame 3 %, a sixteenth 18 %).  Decided with the unit shape in make_launch.
         if (L.pool_slots != 0u) {
             f = L.fold ? c->f_render_pool_fold : c->f_render_pool;
             c->last_kernel = L.fold ? "rt_render_pool_fold" : "rt_render_pool";

@@ -616,11 +616,11 @@ def test_unit_size_does_not_change_the_image(rt, hip):
 
 
 def test_scheduler_is_chosen_by_launch_size_and_does_not_change_the_image(rt, hip):
-    """With every sample its own item the library pools the pixel units per workgroup on launches with few units per
-    resident wavefront (fewer than 128 at max_depth 50, 64 at this test's 12) and leaves them with the wavefronts on large ones.  921,600 one-pixel units are a large
-    launch, the same frame in the library's own units a small one; forced either way the frame is the same, for
-    workgroups of one wavefront (a pool of two units) up to sixteen, and for units with fewer samples than a
-    camera-ray batch."""
+    """With every sample its own item the library pools the pixel units per workgroup on launches with fewer than 2^20
+    samples per resident wavefront and leaves them with the wavefronts on larger ones (the crossover itself is timed on
+    full-size frames in tests/test_zy_scheduler_choice.py).  This 1.8 M-sample frame is a small launch whatever the unit
+    shape; forced either way the frame is the same, for workgroups of one wavefront (a pool of two units) up to
+    sixteen, and for units with fewer samples than a camera-ray batch."""
     sp = rt.scene_book1_final(1)
     cam = rt.Camera.look_at(16.0 / 9.0, 1280, 20.0, (13.0, 2.0, 3.0), (0.0, 0.0, 0.0))
     p = rt.DeviceGUI(samples_per_pixel=2, max_depth=12, seed=6, sample_chunk=1)
@@ -628,6 +628,9 @@ def test_scheduler_is_chosen_by_launch_size_and_does_not_change_the_image(rt, hi
     small = hip.render(cam, p, linear=True)
     assert hip.last_kernel_name() == "rt_render_pool"
     hip.debug_schedule(unit=(1, 1))
+    hip.render(cam, p)
+    assert hip.last_kernel_name() == "rt_render_pool"
+    hip.debug_schedule(unit=(1, 1), scheduler="wave")
     large = hip.render(cam, p, linear=True)
     assert hip.last_kernel_name() == "rt_render_queue"
     hip.debug_schedule()

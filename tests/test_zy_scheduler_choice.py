@@ -1,5 +1,5 @@
 """The library's choice between its two schedulers for sample_chunk = 1 (pixel units held per wavefront:
-rt_render_queue; pooled per workgroup: rt_render_pool) is a rule on the launch size (rt_hip.cpp, make_launch).  This
+rt_render_queue; pooled per workgroup: rt_render_pool) is a rule on the launch size (rt_hip.cpp, make_launch: fewer than 2^20 samples per resident wavefront -> pooled).  This
 walks launch sizes across the rule's threshold -- the whole frame, then rank 0's interleaved row tiles of 2, 4, 8 and 16
 ranks -- on the two frames the rule was fitted on (book scene 3840x2160 at 500 spp, depth 50; mirror hall 7680x4320 at
 256 spp, depth 100), times the render kernel under each forced scheduler and under the library's own choice (HIP events
