@@ -263,9 +263,10 @@ RtLaunch make_launch(const rt_ctx* c, const RtCamera* cam, const RtParams* p, ui
                 const uint64_t items = (uint64_t)L.unit_w * L.unit_h * L.n_chunks, samples = (uint64_t)L.unit_w * L.unit_h * spp;
                 uint32_t w = L.unit_w, h = L.unit_h;
                 if (w < 16u || !height_ok(2u * h)) w *= 2u; else h *= 2u;
-                // (a unit is written as one row segment per row: 16 pixels make it a whole 64-byte line, so a unit that
-                // is large enough still widens to 16 while the launch keeps its units; measured equal in time at every
-                // launch size, and the frame then reaches memory once instead of twice)
+                // (a unit is written as one row segment per row and taken with one atomic add on the work counter, which
+                // the memory side executes: the HBM write counter shows the frame once plus 32 bytes per unit, at any unit
+                // shape.  A unit that is large enough still widens to 16 pixels, a whole 64-byte line per store and half
+                // the atomics of 8; measured equal in time at every launch size.)
                 if (items >= 512u && ((samples >= 2048u && L.unit_w >= 16u) || n_units_with(w, h) < min_units)) break;
                 L.unit_w = w; L.unit_h = h;
             }
