@@ -37,6 +37,8 @@ typedef struct RtLaunch {
     uint32_t pool_slots;       // rt_render_pool: open units per workgroup (LDS pool)
     uint32_t units_bottom_up;  // 1: the wavefronts take the launch's pixel units from the last row upwards
     float    scan_scale;       // sigma of the scan filter: a power of two, sigma * |c - o| <= 1/2 for origins on the scene's spheres
+    uint32_t ulist_cap;        // camera-ray-batch kernels: entries of a pixel unit's sphere list (even, <= 32; 0: no lists)
+    float    unit_reach;       // how far a camera ray's direction can be from the one through the centre of its unit's footprint
 } RtLaunch;
 
 // Launch-wide counter block of the render kernels, device memory, cleared before every launch: sixteen 64-bit
@@ -72,5 +74,7 @@ typedef struct RtLaunch {
 #endif
 #define RT_Q_CAND_CAP 8u
 #define RT_Q_WORDS 8u
+// LDS bytes of a pixel unit's sphere list of `cap` entries: a float4 of camera-ray terms and a u16 index each
+#define RT_UL_BYTES(cap) (((cap) * 18u + 15u) & ~15u)
 
 #endif

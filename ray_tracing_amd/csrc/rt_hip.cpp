@@ -271,16 +271,19 @@ RtLaunch make_launch(const rt_ctx* c, const RtCamera* cam, const RtParams* p, ui
                 L.unit_w = w; L.unit_h = h;
             }
         };
-        // Launches of fewer than 2^20 samples per resident wavefront (24 per compute unit) run with the units pooled per
-        // workgroup (rt_render_pool, see launch_render), where the end of the launch costs little and the units can have
-        // their full size.  Measured with 16x1 units (kernel ms, per-wavefront / pooled): book scene 4K at 500 spp, depth
-        // 50: whole frame = 675 k samples per wavefront 900 / 897, half 454 / 451, an eighth 118 / 114, a sixteenth
-        // 62 / 58; mirror hall 8K at 256 spp, depth 100: whole frame = 1.38 M samples per wavefront 373 / 379, half =
-        // 691 k 194 / 190, a quarter 105 / 96, an eighth 53 / 49.  Only launches as large as the whole hall frame are
-        // faster with the wavefronts holding their own units (the pool's 22 instructions per batch and trip weigh most
-        // where trips are short).
+        // Short launches run with the units pooled per workgroup (rt_render_pool, see launch_render): the end of the launch,
+        // when the wavefronts run out of units one by one, then costs little -- whole workgroups finish the last units --
+        // and the units can have their full size.  In steady state the pooled kernel is 6-8 % behind (more wave-uniform
+        // state than there are scalar registers, and its bookkeeping per camera-ray batch weighs more since the units'
+        // sphere lists shortened the batches).  The crossover is a launch length: about 95 ms of kernel time, estimated
+        // here as samples per resident wavefront (24 per compute unit) x (spheres + 56) < 44 M, a segment's cost being
+        // 9 operations per sphere and some 500 beside the scan.  Measured with 16x1 units (kernel ms, per-wavefront /
+        // pooled; same box): book scene 4K at 500 spp, depth 50 (486 spheres): whole frame = 675 k samples per wavefront
+        // 744 / 790, a quarter 185 / 199, an eighth (84 k x 542 = 46 M) 99.5 / 99.7, a sixteenth 52.4 / 52.5; mirror hall
+        // 8K at 256 spp, depth 100 (66 spheres): whole frame = 1.38 M samples per wavefront 344 / 371, half 177 / 186, a
+        // quarter (345 k x 122 = 42 M) 96.0 / 93.6, an eighth 49.2 / 47.5, a sixteenth 24.5 / 23.9.
         const uint64_t launch_samples = (uint64_t)cam->image_width * rows_local * spp;
-        const bool small_launch = launch_samples < ((uint64_t)resident << 20);
+        const bool small_launch = launch_samples * (c->n_padded + 56u) < resident * 44000000ull;
         const bool pool_able = L.chunk == 1u && L.n_chunks > 1u && queue_kernel_fits(c, cam, spp) && p->max_depth > 0u &&
                                c->n_padded <= RT_TILE_SPHERES && (fold ? c->f_render_pool_fold : c->f_render_pool) != nullptr &&
                                c->dbg_scheduler != RT_SCHED_WAVE;
@@ -316,6 +319,32 @@ RtLaunch make_launch(const rt_ctx* c, const RtCamera* cam, const RtParams* p, ui
     for (L.unit_pshift = 0; (1u << L.unit_pshift) < L.unit_w * L.unit_h; L.unit_pshift++) {}
     L.units_x = (cam->image_width + L.unit_w - 1u) / L.unit_w;
     L.n_units = L.units_x * ((rows_local + L.unit_h - 1u) / L.unit_h);
+    // Sphere lists per pixel unit for the camera-ray batches (unit_list in rt_kernels.hip): up to 32 entries where the
+    // workgroup's LDS has the room (launch_render), none on the kernels that stream the sphere list.  unit_reach: the
+    // largest distance between the direction of a camera ray of a unit and the direction through the centre of the
+    // unit's footprint, (w + 1/2)/2 |du| + (h + 1/2)/2 |dv|, plus twice what make_ray's four roundings per component
+    // can add to either (each below 2^-24 of a partial result; 2^-20 of the sum of all magnitudes is generous), rounded up.
+    L.ulist_cap = 0u;
+    L.unit_reach = 0.0f;
+    if (L.n_chunks > 1u && L.chunk == 1u && c->n_padded <= RT_TILE_SPHERES && queue_kernel_fits(c, cam, spp)) {
+        double nu = 0.0, nv = 0.0, mag = 0.0;
+        for (int k = 0; k < 3; k++) {
+            const double du = cam->pixel_delta_u[k], dv = cam->pixel_delta_v[k];
+            nu += du * du;
+            nv += dv * dv;
+            mag += std::fabs((double)cam->pixel00_loc[k]) + std::fabs((double)cam->center[k]) +
+                   ((double)cam->image_width + 1.0) * std::fabs(du) + ((double)cam->image_height + 1.0) * std::fabs(dv);
+        }
+        const double reach = (0.5 * (L.unit_w + 0.5) * std::sqrt(nu) + 0.5 * (L.unit_h + 0.5) * std::sqrt(nv)) * (1.0 + 0x1p-20) + 2.0 * 0x1p-20 * mag;
+        if (reach == reach && reach < 1e30) {
+            L.unit_reach = std::nextafter((float)reach, INFINITY);
+            L.ulist_cap = 32u;
+        }
+    }
+    if (const char* e = std::getenv("RT_EXP_ULIST_CAP")) {                       // timing experiments only: 0, 16 or 32
+        const unsigned v = (unsigned)std::atoi(e);
+        if (v < L.ulist_cap) L.ulist_cap = v & ~1u;
+    }
     return L;
 }
 
@@ -363,7 +392,25 @@ int launch_render(rt_ctx* c, const RtCamera* cam, const RtParams* p, RtLaunch L,
             waves = block / 64u;
             grid = (L.n_units + waves - 1u) / waves;
         }
-        lds = (one_tile ? c->n_padded : RT_Q_STREAM_TILE) * 32u + waves * (RT_Q_CAND_CAP * 128u + 48u * P + RT_Q_WORDS * 256u);
+        if (!one_tile) L.ulist_cap = 0u;
+        // the unit lists are the first thing to go where a workgroup's LDS (64 KiB) is short: 32 entries, 16, none
+        auto queue_lds = [&](unsigned cap) { return c->n_padded * 32u + waves * (RT_Q_CAND_CAP * 128u + 48u * P + RT_Q_WORDS * 256u + RT_UL_BYTES(cap)); };
+        auto pool_lds = [&](unsigned cap) {
+            return c->n_padded * 32u + 2u * waves * 32u + 16u + 2u * waves * 24u * P + 2u * waves * RT_UL_BYTES(cap) + waves * (RT_Q_CAND_CAP * 128u + RT_Q_WORDS * 256u);
+        };
+        if (one_tile && L.ulist_cap != 0u) {
+            // (and they must not cost a workgroup per compute unit: a wave of occupancy is worth more than long lists)
+            hipFunction_t fq = L.pool_slots ? (L.fold ? c->f_render_pool_fold : c->f_render_pool) : f;
+            auto resident_with = [&](unsigned cap) {
+                const unsigned bytes = L.pool_slots ? pool_lds(cap) : queue_lds(cap);
+                int n = 0;
+                if (bytes > 65536u || hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&n, fq, (int)block, bytes) != hipSuccess) n = 0;
+                return n;
+            };
+            const int without = resident_with(0u);
+            while (L.ulist_cap != 0u && resident_with(L.ulist_cap) < without) L.ulist_cap = L.ulist_cap > 16u ? 16u : 0u;
+        }
+        lds = one_tile ? queue_lds(L.ulist_cap) : RT_Q_STREAM_TILE * 32u + waves * (RT_Q_CAND_CAP * 128u + 48u * P + RT_Q_WORDS * 256u);
         // Who holds the open pixel units: each wavefront two of its own (rt_render_queue), or the workgroup a pool of
         // them from which all its wavefronts take camera rays (rt_render_pool).  The pool costs about 22 more
         // instructions per batch and trip (level on the 4K book frame, 3 % slower on the 8K mirror hall), but no wavefront
@@ -375,7 +422,7 @@ int launch_render(rt_ctx* c, const RtCamera* cam, const RtParams* p, RtLaunch L,
             // as many open units as the wavefronts would hold between them, so the same LDS: slot headers, the
             // control words, the slots' accumulators, and per wavefront the candidate lists and the ray queue
             L.pool_slots = 2u * waves;
-            lds = c->n_padded * 32u + L.pool_slots * 32u + 16u + L.pool_slots * 24u * P + waves * (RT_Q_CAND_CAP * 128u + RT_Q_WORDS * 256u);
+            lds = pool_lds(L.ulist_cap);
             grid = L.n_units;                                    // a unit is work for a whole workgroup
         }
     } else {

@@ -205,7 +205,10 @@ RT_DEV void drain(const Tile& tile, int base, Cand& c, V3 o, V3 d, float a, floa
 
 // The clear bits of one block's mask (bit j: sphere blk + (k-1-j)) become entries of the lanes' candidate
 // lists, lowest sphere index first; full lists are drained on the spot.
-RT_DEV void decode_block(const Tile& tile, int base, uint32_t blk, uint32_t k, uint32_t miss,
+// MAPPED with map != NULL (wave-uniform): the scanned entries are a pixel unit's list (unit_list) and map[] holds
+// their sphere indices, ascending.
+template <bool MAPPED>
+RT_DEV void decode_block(const Tile& tile, int base, uint32_t blk, uint32_t k, uint32_t miss, const uint16_t* map,
                          V3 o, V3 d, float a, float t_min, Best& b, Cand& c, Stats& st) {
     uint32_t bits = ~miss & (k == 32u ? 0xffffffffu : ((1u << k) - 1u));
 #ifdef RT_EXP_DECODE2
@@ -227,7 +230,9 @@ RT_DEV void decode_block(const Tile& tile, int base, uint32_t blk, uint32_t k, u
         st.wave(4);
         st.add(2, 1u);
         uint32_t pos = 31u - (uint32_t)__clz((int)bits);            // highest bit = lowest sphere index first
-        push(c, blk + (k - 1u - pos));
+        uint32_t idx = blk + (k - 1u - pos);
+        if (MAPPED && map) idx = map[idx];
+        push(c, idx);
         bits &= ~(1u << pos);
         // a full list: the lanes still decoding drain theirs together (the others' lists have room left)
         if (__ballot(c.n >= c.cap) != 0ull) { st.lap(10); drain(tile, base, c, o, d, a, t_min, b, st); st.lap(11); }
@@ -327,7 +332,7 @@ RT_DEV void scan_tile(const Tile& tile, uint32_t count, int base, V3 T, float si
 #pragma unroll
         for (uint32_t i = 0; i < 32u; i += RT_SCAN_UNROLL) filter_step<HALF, RT_SCAN_UNROLL>(r, tile.geo + blk + i, miss);
         st.lap(9);
-        decode_block(tile, base, blk, 32u, miss, o, d, a, t_min, b, c, st);
+        decode_block<false>(tile, base, blk, 32u, miss, nullptr, o, d, a, t_min, b, c, st);
     }
     if (blk < count) {                                                 // the last 2 .. 30 spheres (count is even)
         const uint32_t k = count - blk;
@@ -336,7 +341,7 @@ RT_DEV void scan_tile(const Tile& tile, uint32_t count, int base, V3 T, float si
         if (k & 4u) { filter_step<HALF, 4u>(r, tile.geo + blk + i, miss); i += 4u; }
         if (k & 2u) filter_step<HALF, 2u>(r, tile.geo + blk + i, miss);
         st.lap(9);
-        decode_block(tile, base, blk, k, miss, o, d, a, t_min, b, c, st);
+        decode_block<false>(tile, base, blk, k, miss, nullptr, o, d, a, t_min, b, c, st);
     }
     drain(tile, base, c, o, d, a, t_min, b, st);
     st.lap(11);
@@ -380,7 +385,9 @@ RT_DEV void primary_step(float fx, float fy, float iLs, const float4* p, uint32_
     }
 }
 
-RT_DEV void scan_primary(const float4* __restrict__ geo0, const Tile& tile, uint32_t count, int base,
+// geo0: `count` entries {A, B, C, sq} in LDS -- the tile's spheres (map = NULL), or a pixel unit's list with the
+// spheres' indices in map[] (unit_list below).
+RT_DEV void scan_primary(const float4* geo0, const uint16_t* map, const Tile& tile, uint32_t count, int base,
                          float fx, float fy, V3 o, V3 d, float a, float t_min, Best& b, Cand& c, Stats& st) {
     st.wave(0);
     const float iLs = filter_inv_len(a);
@@ -390,7 +397,7 @@ RT_DEV void scan_primary(const float4* __restrict__ geo0, const Tile& tile, uint
 #pragma unroll
         for (uint32_t i = 0; i < 32u; i += RT_SCAN_UNROLL) primary_step<RT_SCAN_UNROLL>(fx, fy, iLs, geo0 + blk + i, miss);
         st.lap(15);
-        decode_block(tile, base, blk, 32u, miss, o, d, a, t_min, b, c, st);
+        decode_block<true>(tile, base, blk, 32u, miss, map, o, d, a, t_min, b, c, st);
     }
     if (blk < count) {
         const uint32_t k = count - blk;
@@ -399,10 +406,76 @@ RT_DEV void scan_primary(const float4* __restrict__ geo0, const Tile& tile, uint
         if (k & 4u) { primary_step<4u>(fx, fy, iLs, geo0 + blk + i, miss); i += 4u; }
         if (k & 2u) primary_step<2u>(fx, fy, iLs, geo0 + blk + i, miss);
         st.lap(15);
-        decode_block(tile, base, blk, k, miss, o, d, a, t_min, b, c, st);
+        decode_block<true>(tile, base, blk, k, miss, map, o, d, a, t_min, b, c, st);
     }
     drain(tile, base, c, o, d, a, t_min, b, st);
     st.lap(11);
+}
+
+// The camera rays of one pixel unit see few spheres, and all of its rays nearly the same ones (16 pixels x some
+// hundred samples, each ray within half a pixel of its pixel's centre).  So the scan over the whole list is done once
+// per UNIT instead of once per 64 rays: unit_list runs scan_primary's test with the image coordinates replaced by
+// whichever corner of the unit's footprint maximises the sphere's dq, and with an upper bound of iLs for the
+// footprint; the spheres that pass -- a superset of what any ray of the unit can list -- are copied, terms and index,
+// to a short list in LDS, lowest index first, and the unit's camera-ray batches scan that list instead of the scene
+// (scan_primary with the list's terms and index map).  Nothing changes in what the exact test sees, except that it sees it sooner.
+//   footprint: fx in [x0 - 1/2, x0 + w], fy in [y0 - 1/2, y0 + h] (sample_ray: pixel + jitter in [-1/2, 1/2), or the grid
+//   sampler's [0, 1)); fx*, fy* = the upper end where the sphere's A (B) is positive, the lower end otherwise.
+//   dq: fl(fx A + fl(fy B + C)) is monotone in fx A and in fy B (products exact, roundings monotone), so
+//   dq(fx*, fy*) >= dq(fx, fy) for every ray of the unit, also after the clamp.
+//   iLs: every ray's direction is within reach = (w + 1/2)/2 |du| + (h + 1/2)/2 |dv| of the direction through the
+//   footprint's centre, both as make_ray rounds them (RtLaunch.unit_reach adds twice the bound of those roundings), so
+//   |d| >= len_min = |d_centre| (1 - 2^-20) - reach and iLs(ray) = rsq(d.d)(1 + 2^-19) <= rsq(len_min^2 (1 - 2^-20))
+//   (1 + 2^-19)(1 + 2^-18) = iL, the 2^-18 covering rsq's 1-ulp error at both ends and the rounding of d.d.
+//   key = fma(dq*, iL, -sq) >= fma(dq, iLs, -sq) then (dq, iLs >= 0), and a product of non-negative factors plus -sq
+//   is never -0 unless the ray's is too: sign clear for the ray => sign clear for the unit.
+// No list (RT_UL_NONE; the batches scan the scene as before) if len_min <= 0 -- a degenerate camera, where rays may
+// have d.d = 0 and NaN keys --, or if more spheres pass than the list holds.
+#define RT_UL_NONE 0xffffffffu
+
+RT_DEV void ray_through(const RtCamera& cam, float fx, float fy, V3& o, V3& d);
+
+RT_DEV uint32_t uniform_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
+struct UnitList { float4* terms; uint16_t* idx; };             // RtLaunch.ulist_cap entries each, per wavefront or pool slot
+
+RT_DEV uint32_t unit_list(const float4* geo0, const RtCamera& cam, const RtLaunch& L, uint32_t x0, uint32_t y0,
+                          const UnitList& ul, uint32_t lane) {
+    const float fx_lo = (float)x0 - 0.5f, fx_hi = (float)(x0 + L.unit_w);
+    const float fy_lo = (float)y0 - 0.5f, fy_hi = (float)(y0 + L.unit_h);
+    V3 o, dc;
+    ray_through(cam, 0.5f * (fx_lo + fx_hi), 0.5f * (fy_lo + fy_hi), o, dc);
+    const float len_min = sqrtf(vdot(dc, dc)) * (1.0f - 0x1p-20f) - L.unit_reach;
+    if (!(len_min > 0.0f)) return RT_UL_NONE;                     // wave-uniform: every operand is
+    const float iL = filter_inv_len((len_min * len_min) * (1.0f - 0x1p-20f)) * (1.0f + 0x1p-18f);
+    uint32_t n = 0u;
+    for (uint32_t first = 0u; first < L.n_padded; first += 64u) {
+        const uint32_t i = first + lane;
+        bool pass = false;
+        float4 t = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (i < L.n_padded) {
+            t = geo0[i];
+            const float fxs = (__float_as_uint(t.x) >> 31) ? fx_lo : fx_hi;
+            const float fys = (__float_as_uint(t.y) >> 31) ? fy_lo : fy_hi;
+            const float dq = __builtin_amdgcn_fmed3f(fmaf(fxs, t.x, fmaf(fys, t.y, t.z)), 0.0f, 1.0f);
+            const float key = fmaf(dq, iL, -t.w);
+            pass = (__float_as_uint(key) >> 31) == 0u;
+        }
+        const unsigned long long m = __ballot(pass);
+        const uint32_t cnt = (uint32_t)__popcll(m);
+        if (n + cnt > L.ulist_cap) return RT_UL_NONE;
+        if (pass) {
+            const uint32_t r = n + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            ul.terms[r] = t;
+            ul.idx[r] = (uint16_t)i;
+        }
+        n += cnt;
+    }
+    if (n & 1u) {                                                 // even, as the scans' last step wants it (the capacity is even)
+        if (lane == 0u) { ul.terms[n] = make_float4(0.0f, 0.0f, 0.0f, INFINITY); ul.idx[n] = 0u; }
+        n++;
+    }
+    return n;
 }
 
 // ---------------------------------------------------------------- shading
@@ -513,15 +586,19 @@ RT_DEV V3 scatter(uint32_t mat, float param, const float4* __restrict__ glass_te
 }
 
 // Primary ray of pixel (i,j) with sub-pixel offset (si,sj): ray.cu:62-77 / lib.rs:215-217.
-RT_DEV void make_ray(const RtCamera& cam, uint32_t i, uint32_t j, float si, float sj, V3& o, V3& d, float& fx, float& fy) {
-    fx = (float)i + si;
-    fy = (float)j + sj;
+RT_DEV void ray_through(const RtCamera& cam, float fx, float fy, V3& o, V3& d) {
     V3 pc;
     pc.x = cam.pixel00_loc[0] + fmaf(cam.pixel_delta_u[0], fx, cam.pixel_delta_v[0] * fy);
     pc.y = cam.pixel00_loc[1] + fmaf(cam.pixel_delta_u[1], fx, cam.pixel_delta_v[1] * fy);
     pc.z = cam.pixel00_loc[2] + fmaf(cam.pixel_delta_u[2], fx, cam.pixel_delta_v[2] * fy);
     o = ld3(cam.center);
     d = vsub(pc, o);
+}
+
+RT_DEV void make_ray(const RtCamera& cam, uint32_t i, uint32_t j, float si, float sj, V3& o, V3& d, float& fx, float& fy) {
+    fx = (float)i + si;
+    fy = (float)j + sj;
+    ray_through(cam, fx, fy, o, d);
 }
 
 RT_DEV void sample_ray(const RtCamera& cam, const RtLaunch& L, uint64_t seed, uint32_t x, uint32_t y,
@@ -1016,7 +1093,7 @@ RT_DEV uint32_t queue_rays(uint32_t* q, bool cont, const Path& p, uint32_t s, ui
 RT_DEV void primary_batch(const Scene& sc, const Tile& tile, const float4* __restrict__ geo0, const RtCamera& cam,
                           const RtLaunch& L, uint64_t seed, V3 T, const Slot& u, uint32_t slot, uint32_t first,
                           uint32_t n_samp, unsigned long long* acc, float4* fold, uint32_t* q, Cand& cand,
-                          uint32_t& queued, uint32_t& completed, uint32_t& nseg, Stats& st) {
+                          const UnitList& ul, uint32_t ul_k, uint32_t& queued, uint32_t& completed, uint32_t& nseg, Stats& st) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t P = L.unit_w * L.unit_h;
     const uint32_t sidx = first + lane;
@@ -1041,9 +1118,14 @@ RT_DEV void primary_batch(const Scene& sc, const Tile& tile, const float4* __res
         b.t = L.t_max;
         b.idx = -1;
         st.lap(14);
-        scan_primary(geo0, tile, L.n_padded, 0, fx, fy, p.o, p.d, vdot(p.d, p.d), L.t_min, b, cand, st);
+        // ul_k (wave-uniform): entries of the unit's list, or RT_UL_NONE: the whole scene
+        const bool listed = ul_k != RT_UL_NONE;
+        const float4* terms = listed ? ul.terms : geo0;
+        const uint16_t* map = listed ? ul.idx : nullptr;
+        const uint32_t n_terms = listed ? ul_k : L.n_padded;
+        scan_primary(terms, map, tile, n_terms, 0, fx, fy, p.o, p.d, vdot(p.d, p.d), L.t_min, b, cand, st);
 #ifdef RT_EXP_PRIMARY2
-        scan_primary(geo0, tile, L.n_padded, 0, fx, fy, p.o, p.d, vdot(p.d, p.d), L.t_min, b, cand, st);   // cost experiment: changes nothing (strict bound)
+        scan_primary(terms, map, tile, n_terms, 0, fx, fy, p.o, p.d, vdot(p.d, p.d), L.t_min, b, cand, st);   // cost experiment: changes nothing (strict bound)
 #endif
         nseg++;
         sphere = (uint32_t)b.idx;
@@ -1075,13 +1157,18 @@ RT_DEV void render_queue_body(const Scene& sc, uint32_t* __restrict__ rgba, floa
 
     float4* geo = rt_lds;
     float4* geo0 = rt_lds + S;
-    char* mine = reinterpret_cast<char*>(geo0 + S) + wave * (RT_Q_CAND_CAP * 128u + 48u * P + RT_Q_WORDS * 256u);
+    char* mine = reinterpret_cast<char*>(geo0 + S) + wave * (RT_Q_CAND_CAP * 128u + 48u * P + RT_Q_WORDS * 256u + RT_UL_BYTES(L.ulist_cap));
     Cand cand;
     cand.col = reinterpret_cast<uint16_t*>(mine) + lane;
     cand.n = 0u;
     cand.cap = RT_Q_CAND_CAP;
     unsigned long long* accum = reinterpret_cast<unsigned long long*>(mine + RT_Q_CAND_CAP * 128u);
     uint32_t* q = reinterpret_cast<uint32_t*>(mine + RT_Q_CAND_CAP * 128u + 48u * P);
+    // the list of the unit whose camera rays are being traced (unit_list)
+    UnitList ul;
+    ul.terms = reinterpret_cast<float4*>(mine + RT_Q_CAND_CAP * 128u + 48u * P + RT_Q_WORDS * 256u);
+    ul.idx = reinterpret_cast<uint16_t*>(ul.terms + L.ulist_cap);
+    uint32_t ul_k = RT_UL_NONE;
     for (uint32_t k = lane; k < 6u * P; k += 64u) accum[k] = 0ull;
     // fold-order mode: this wavefront's [2 slots][P][samples_per_pixel] colours in the launch's workspace
     float4* fold = FOLD ? fold_all + (size_t)(blockIdx.x * (blockDim.x >> 6) + wave) * (2u * P * (size_t)L.samples_per_pixel) : nullptr;
@@ -1147,13 +1234,14 @@ RT_DEV void render_queue_body(const Scene& sc, uint32_t* __restrict__ rgba, floa
                         next_samp = 0u;
                         if (cur) u1 = open_unit(L, unit, n_samp); else u0 = open_unit(L, unit, n_samp);
                         if (n_samp == 0u) continue;
+                        ul_k = L.ulist_cap ? uniform_u32(unit_list(geo0, cam, L, cur ? u1.x0 : u0.x0, cur ? u1.y0 : u0.y0, ul, lane)) : RT_UL_NONE;
                     }
                 }
             }
             if (can) {
                 uint32_t completed = 0u;
                 primary_batch(sc, tile, geo0, cam, L, seed, T, cur ? u1 : u0, cur, next_samp, n_samp,
-                              accum, fold, q, cand, q_count, completed, nseg, st);
+                              accum, fold, q, cand, ul, ul_k, q_count, completed, nseg, st);
                 q_head = 0u;
                 next_samp = next_samp + 64u < n_samp ? next_samp + 64u : n_samp;
                 if (cur) u1.left -= completed; else u0.left -= completed;
@@ -1211,17 +1299,16 @@ RT_DEV void render_queue_body(const Scene& sc, uint32_t* __restrict__ rgba, floa
 // hold up one pool slot, not the wavefront that traced them -- a wavefront never waits for its own stragglers before it
 // may start new camera rays; (2) at the end of the launch the workgroup's wavefronts finish the last units together
 // instead of each finishing two of its own.  The image is the same bit for bit: sums are exact and order-free.
-//   slot (8 words): x0, y0 (global row), ly0 (local row), next sample to trace, samples not yet finished, open flag
+//   slot (8 words): x0, y0 (global row), ly0 (local row), next sample to trace, samples not yet finished, open flag,
+//        entries of the unit's list (unit_list; RT_UL_NONE: none)
 //   ctl: [0] slot the camera rays are taken from (POOL_NONE before the first unit, POOL_DRAINED when the launch's
 //        counter has run out), [1] lock of the wavefront that is opening a unit
-//   LDS: [geo S float4][geo0 S float4][slots NS x 8 u32][ctl 4 u32][accumulators NS x P x 3 u64] then per wavefront
-//        [candidate lists RT_Q_CAND_CAP x 64 u16][queue RT_Q_WORDS x 64 u32]
+//   LDS: [geo S float4][geo0 S float4][slots NS x 8 u32][ctl 4 u32][accumulators NS x P x 3 u64][unit lists NS x
+//        RT_UL_BYTES] then per wavefront [candidate lists RT_Q_CAND_CAP x 64 u16][queue RT_Q_WORDS x 64 u32]
 // A finished sample is added to its pixel's accumulators and then taken off its slot's count (LDS operations of a
 // wavefront are performed in order); whoever takes the last one off writes the unit's pixels and frees the slot.
 #define POOL_NONE 0xffffffffu
 #define POOL_DRAINED 0xfffffffeu
-
-RT_DEV uint32_t uniform_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
 // Opens the workgroup's next unit and makes it the one camera rays are taken from, if nobody else is at it.
 // ahead = POOL_NONE: the caller found the current unit used up (or none there yet).  ahead = a slot: the caller holds
@@ -1229,8 +1316,17 @@ RT_DEV uint32_t uniform_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_read
 // do not find themselves without camera rays for the time the launch's counter takes to answer; wavefronts go on
 // taking the older unit's last batches from the slot they remember (pool_next_batch).
 // Returns true if it makes sense to look at the control word again right away.
+// The list of pool slot `slot` (the workgroup's LDS layout: see render_pool_body).
+RT_DEV UnitList pool_list(const RtLaunch& L, uint32_t slot) {
+    char* base = reinterpret_cast<char*>(rt_lds + 2u * L.n_padded) + L.pool_slots * (32u + 24u * L.unit_w * L.unit_h) + 16u;
+    UnitList ul;
+    ul.terms = reinterpret_cast<float4*>(base + slot * RT_UL_BYTES(L.ulist_cap));
+    ul.idx = reinterpret_cast<uint16_t*>(ul.terms + L.ulist_cap);
+    return ul;
+}
+
 RT_DEV bool pool_open(const RtLaunch& L, uint32_t* slots, uint32_t* ctl, uint32_t* __restrict__ work, uint32_t n_samp,
-                      uint32_t lane, uint32_t ahead, bool& drained) {
+                      uint32_t lane, uint32_t ahead, const RtCamera& cam, bool& drained) {
     uint32_t lock = 1u;
     if (lane == 0u) lock = atomicCAS(&ctl[1], 0u, 1u);
     if (uniform_u32(lock) != 0u) return false;                    // somebody is opening one
@@ -1262,7 +1358,10 @@ RT_DEV bool pool_open(const RtLaunch& L, uint32_t* slots, uint32_t* ctl, uint32_
                 }
             } else {
                 const Slot u = open_unit(L, unit, n_samp);
+                // the free slot's list is nobody's: written here, published with the slot below
+                const uint32_t ul_k = L.ulist_cap ? uniform_u32(unit_list(rt_lds + L.n_padded, cam, L, u.x0, u.y0, pool_list(L, f), lane)) : RT_UL_NONE;
                 if (lane == 0u) {
+                    slots[f * 8u + 6u] = ul_k;
                     slots[f * 8u + 0u] = u.x0;
                     slots[f * 8u + 1u] = u.y0;
                     slots[f * 8u + 2u] = u.ly0;
@@ -1284,8 +1383,8 @@ RT_DEV bool pool_open(const RtLaunch& L, uint32_t* slots, uint32_t* ctl, uint32_
 // still held by unfinished paths, or the launch's counter has run out: `drained`).
 // ahead_at: the wavefront whose batch contains this sample of a unit opens the next unit (pool_open).
 RT_DEV bool pool_next_batch(const RtLaunch& L, uint32_t* slots, uint32_t* ctl, uint32_t* __restrict__ work, uint32_t n_samp,
-                            uint32_t ahead_at, uint32_t lane, uint32_t& hint, uint32_t& slot, uint32_t& first, uint4& head,
-                            bool& drained) {
+                            uint32_t ahead_at, uint32_t lane, const RtCamera& cam, uint32_t& hint, uint32_t& slot, uint32_t& first,
+                            uint4& head, bool& drained) {
     bool got = false;
     // The slot this wavefront last took a batch from is tried first.  A unit that still has untraced samples is good
     // to take from whatever the control word says (a slot's counter is set to 0 only after its other fields, and
@@ -1321,11 +1420,11 @@ RT_DEV bool pool_next_batch(const RtLaunch& L, uint32_t* slots, uint32_t* ctl, u
             }
         }
         // the current unit is used up (or there is none yet): open the next one, if nobody else is at it
-        if (!pool_open(L, slots, ctl, work, n_samp, lane, POOL_NONE, drained)) return false;
+        if (!pool_open(L, slots, ctl, work, n_samp, lane, POOL_NONE, cam, drained)) return false;
     }
     if (got && ahead_at >= first && ahead_at < first + 64u) {
         bool unused = false;
-        (void)pool_open(L, slots, ctl, work, n_samp, lane, slot, unused);
+        (void)pool_open(L, slots, ctl, work, n_samp, lane, slot, cam, unused);
     }
     return got;
 }
@@ -1373,7 +1472,7 @@ RT_DEV void render_pool_body(const Scene& sc, uint32_t* __restrict__ rgba, float
     uint32_t* slots = reinterpret_cast<uint32_t*>(geo0 + S);
     uint32_t* ctl = slots + NS * 8u;
     unsigned long long* accum = reinterpret_cast<unsigned long long*>(ctl + 4u);
-    char* mine = reinterpret_cast<char*>(accum + NS * 3u * P) + wave * (RT_Q_CAND_CAP * 128u + RT_Q_WORDS * 256u);
+    char* mine = reinterpret_cast<char*>(accum + NS * 3u * P) + NS * RT_UL_BYTES(L.ulist_cap) + wave * (RT_Q_CAND_CAP * 128u + RT_Q_WORDS * 256u);
     Cand cand;
     cand.col = reinterpret_cast<uint16_t*>(mine) + lane;
     cand.n = 0u;
@@ -1440,14 +1539,17 @@ RT_DEV void render_pool_body(const Scene& sc, uint32_t* __restrict__ rgba, float
         if (want != 0ull && !drained) {
             uint32_t sl = 0u, first = 0u;
             uint4 head = make_uint4(0u, 0u, 0u, 0u);
-            if (pool_next_batch(L, slots, ctl, work, n_samp, ahead_at, lane, hint, sl, first, head, drained)) {
+            if (pool_next_batch(L, slots, ctl, work, n_samp, ahead_at, lane, cam, hint, sl, first, head, drained)) {
                 Slot u;
                 u.open = true; u.left = 0u;
                 u.x0 = uniform_u32(head.x);
                 u.y0 = uniform_u32(head.y);
                 u.ly0 = uniform_u32(head.z);
                 uint32_t completed = 0u;
-                primary_batch(sc, tile, geo0, cam, L, seed, T, u, sl, first, n_samp, accum, fold, q, cand, q_count, completed, nseg, st);
+                // (the list's length sits in the slot like x0: once the batch is this wavefront's the slot cannot change hands)
+                const uint32_t ul_k = uniform_u32(slots[sl * 8u + 6u]);
+                primary_batch(sc, tile, geo0, cam, L, seed, T, u, sl, first, n_samp, accum, fold, q, cand, pool_list(L, sl), ul_k,
+                              q_count, completed, nseg, st);
                 q_head = 0u;
                 if (completed) pool_finish(L, slots, accum, sl, completed, lane, rgba, linear, fold);
                 continue;
@@ -1639,9 +1741,9 @@ RT_DEV void render_queue_stream_body(const Scene& sc, uint32_t* __restrict__ rgb
                 __syncthreads();
                 const Tile tile = {geo, sc.exact + first};       // exact-test data from global memory
                 if (traced) {
-                    scan_primary(geo0, tile, count, (int)first, bfx, bfy, co, bd, ba, L.t_min, b, cand, st);
+                    scan_primary(geo0, nullptr, tile, count, (int)first, bfx, bfy, co, bd, ba, L.t_min, b, cand, st);
 #ifdef RT_EXP_PRIMARY2
-                    scan_primary(geo0, tile, count, (int)first, bfx, bfy, co, bd, ba, L.t_min, b, cand, st);   // cost experiment
+                    scan_primary(geo0, nullptr, tile, count, (int)first, bfx, bfy, co, bd, ba, L.t_min, b, cand, st);   // cost experiment
 #endif
                 }
             }

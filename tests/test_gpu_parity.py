@@ -616,8 +616,8 @@ def test_unit_size_does_not_change_the_image(rt, hip):
 
 
 def test_scheduler_is_chosen_by_launch_size_and_does_not_change_the_image(rt, hip):
-    """With every sample its own item the library pools the pixel units per workgroup on launches with fewer than 2^20
-    samples per resident wavefront and leaves them with the wavefronts on larger ones (the crossover itself is timed on
+    """With every sample its own item the library pools the pixel units per workgroup on short launches (an estimate of the
+    launch's work per resident wavefront, rt_hip.cpp make_launch) and leaves them with the wavefronts on larger ones (the crossover itself is timed on
     full-size frames in tests/test_zy_scheduler_choice.py).  This 1.8 M-sample frame is a small launch whatever the unit
     shape; forced either way the frame is the same, for workgroups of one wavefront (a pool of two units) up to
     sixteen, and for units with fewer samples than a camera-ray batch."""

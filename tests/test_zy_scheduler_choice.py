@@ -1,5 +1,5 @@
 """The library's choice between its two schedulers for sample_chunk = 1 (pixel units held per wavefront:
-rt_render_queue; pooled per workgroup: rt_render_pool) is a rule on the launch size (rt_hip.cpp, make_launch: fewer than 2^20 samples per resident wavefront -> pooled).  This
+rt_render_queue; pooled per workgroup: rt_render_pool) is a rule on the launch size (rt_hip.cpp, make_launch: short launches -> pooled).  This
 walks launch sizes across the rule's threshold -- the whole frame, then rank 0's interleaved row tiles of 2, 4, 8 and 16
 ranks -- on the two frames the rule was fitted on (book scene 3840x2160 at 500 spp, depth 50; mirror hall 7680x4320 at
 256 spp, depth 100), times the render kernel under each forced scheduler and under the library's own choice (HIP events
@@ -17,7 +17,7 @@ def test_library_picks_the_faster_scheduler_across_launch_sizes():
     from ray_tracing_amd import tiles
     cases = [("book", rt.scene_book1_final(1), rt.Camera.look_at(16.0 / 9.0, 3840, 20.0, (13.0, 2.0, 3.0), (0.0, 0.0, 0.0)), 500, 50),
              ("hall", rt.scene_mirror_hall(3, 64), rt.Camera.look_at(16.0 / 9.0, 7680, 90.0, (0.0, 0.0, -85.0), (0.0, 0.0, -70.0)), 256, 100)]
-    report = []
+    report, late = [], []
     for name, sp, cam, spp, depth in cases:
         H, W = cam.image_height, cam.image_width
         p = rt.DeviceGUI(samples_per_pixel=spp, max_depth=depth, seed=1, sample_chunk=1)
@@ -40,5 +40,7 @@ def test_library_picks_the_faster_scheduler_across_launch_sizes():
                 assert rays["wave"] == rays["pool"] == rays["auto"] and sums["wave"] == sums["pool"] == sums["auto"]
                 fastest = min(ms["wave"], ms["pool"])
                 report.append(f"{name} 1/{world}: wave {ms['wave']:.1f} ms, pool {ms['pool']:.1f} ms, library ({kernel['auto']}) {ms['auto']:.1f} ms")
-                assert ms["auto"] <= 1.02 * fastest + 0.2, report[-1]
+                if ms["auto"] > 1.02 * fastest + 0.2:
+                    late.append(report[-1])
     print("\n".join(report))
+    assert not late, late
