@@ -319,29 +319,33 @@ RtLaunch make_launch(const rt_ctx* c, const RtCamera* cam, const RtParams* p, ui
     for (L.unit_pshift = 0; (1u << L.unit_pshift) < L.unit_w * L.unit_h; L.unit_pshift++) {}
     L.units_x = (cam->image_width + L.unit_w - 1u) / L.unit_w;
     L.n_units = L.units_x * ((rows_local + L.unit_h - 1u) / L.unit_h);
-    // Sphere lists per pixel unit for the camera-ray batches (unit_list in rt_kernels.hip): up to 32 entries where the
-    // workgroup's LDS has the room (launch_render), none on the kernels that stream the sphere list.  unit_reach: the
-    // largest distance between the direction of a camera ray of a unit and the direction through the centre of the
-    // unit's footprint, (w + 1/2)/2 |du| + (h + 1/2)/2 |dv|, plus twice what make_ray's four roundings per component
-    // can add to either (each below 2^-24 of a partial result; 2^-20 of the sum of all magnitudes is generous), rounded up.
+    // Sphere lists per pixel unit for the camera-ray batches (unit_list in rt_kernels.hip): 16 entries where the
+    // workgroup's LDS has the room (launch_render).  unit_reach: the largest distance between the direction of a camera
+    // ray of a unit, as make_ray rounds it, and the exact direction through the centre of the unit's footprint:
+    // (w + 1/2)/2 |du| + (h + 1/2)/2 |dv| + eta, eta bounding make_ray's four roundings per component (each below 2^-24
+    // of a partial result: 2^-24 (|pixel00_k| + |pixel00_k - o_k| + 3 (W+1) |du_k| + 4 (H+1) |dv_k|), as in
+    // rt_camera_terms), rounded up.
     L.ulist_cap = 0u;
     L.unit_reach = 0.0f;
-    if (L.n_chunks > 1u && L.chunk == 1u && c->n_padded <= RT_TILE_SPHERES && queue_kernel_fits(c, cam, spp)) {
-        double nu = 0.0, nv = 0.0, mag = 0.0;
+    // (a list costs some 400 operations per unit to set up and saves 4 per sphere and batch: not worth it for a handful of spheres)
+    if (L.n_chunks > 1u && L.chunk == 1u && c->n_padded >= 16u && queue_kernel_fits(c, cam, spp)) {
+        double nu = 0.0, nv = 0.0, eta = 0.0;
+        const double W1 = (double)cam->image_width + 1.0, H1 = (double)cam->image_height + 1.0;
         for (int k = 0; k < 3; k++) {
             const double du = cam->pixel_delta_u[k], dv = cam->pixel_delta_v[k];
             nu += du * du;
             nv += dv * dv;
-            mag += std::fabs((double)cam->pixel00_loc[k]) + std::fabs((double)cam->center[k]) +
-                   ((double)cam->image_width + 1.0) * std::fabs(du) + ((double)cam->image_height + 1.0) * std::fabs(dv);
+            const double e = 0x1p-24 * (std::fabs((double)cam->pixel00_loc[k]) + std::fabs((double)cam->pixel00_loc[k] - (double)cam->center[k]) +
+                                        3.0 * W1 * std::fabs(du) + 4.0 * H1 * std::fabs(dv));
+            eta += e * e;
         }
-        const double reach = (0.5 * (L.unit_w + 0.5) * std::sqrt(nu) + 0.5 * (L.unit_h + 0.5) * std::sqrt(nv)) * (1.0 + 0x1p-20) + 2.0 * 0x1p-20 * mag;
+        const double reach = (0.5 * (L.unit_w + 0.5) * std::sqrt(nu) + 0.5 * (L.unit_h + 0.5) * std::sqrt(nv) + std::sqrt(eta)) * (1.0 + 0x1p-20);
         if (reach == reach && reach < 1e30) {
             L.unit_reach = std::nextafter((float)reach, INFINITY);
-            L.ulist_cap = 32u;
+            L.ulist_cap = 16u;
         }
     }
-    if (const char* e = std::getenv("RT_EXP_ULIST_CAP")) {                       // timing experiments only: 0, 16 or 32
+    if (const char* e = std::getenv("RT_EXP_ULIST_CAP")) {                       // timing experiments only: 0 .. 16
         const unsigned v = (unsigned)std::atoi(e);
         if (v < L.ulist_cap) L.ulist_cap = v & ~1u;
     }
@@ -392,13 +396,14 @@ int launch_render(rt_ctx* c, const RtCamera* cam, const RtParams* p, RtLaunch L,
             waves = block / 64u;
             grid = (L.n_units + waves - 1u) / waves;
         }
-        if (!one_tile) L.ulist_cap = 0u;
-        // the unit lists are the first thing to go where a workgroup's LDS (64 KiB) is short: 32 entries, 16, none
-        auto queue_lds = [&](unsigned cap) { return c->n_padded * 32u + waves * (RT_Q_CAND_CAP * 128u + 48u * P + RT_Q_WORDS * 256u + RT_UL_BYTES(cap)); };
+        // the unit lists are the first thing to go where a workgroup's LDS (64 KiB) is short: 16 entries, 8, none
+        auto queue_lds = [&](unsigned cap) {
+            return (one_tile ? c->n_padded : RT_Q_STREAM_TILE) * 32u + waves * (RT_Q_CAND_CAP * 128u + 48u * P + RT_Q_WORDS * 256u + RT_UL_BYTES(cap));
+        };
         auto pool_lds = [&](unsigned cap) {
             return c->n_padded * 32u + 2u * waves * 32u + 16u + 2u * waves * 24u * P + 2u * waves * RT_UL_BYTES(cap) + waves * (RT_Q_CAND_CAP * 128u + RT_Q_WORDS * 256u);
         };
-        if (one_tile && L.ulist_cap != 0u) {
+        if (L.ulist_cap != 0u) {
             // (and they must not cost a workgroup per compute unit: a wave of occupancy is worth more than long lists)
             hipFunction_t fq = L.pool_slots ? (L.fold ? c->f_render_pool_fold : c->f_render_pool) : f;
             auto resident_with = [&](unsigned cap) {
@@ -408,9 +413,9 @@ int launch_render(rt_ctx* c, const RtCamera* cam, const RtParams* p, RtLaunch L,
                 return n;
             };
             const int without = resident_with(0u);
-            while (L.ulist_cap != 0u && resident_with(L.ulist_cap) < without) L.ulist_cap = L.ulist_cap > 16u ? 16u : 0u;
+            while (L.ulist_cap != 0u && resident_with(L.ulist_cap) < without) L.ulist_cap = L.ulist_cap > 8u ? 8u : 0u;
         }
-        lds = one_tile ? queue_lds(L.ulist_cap) : RT_Q_STREAM_TILE * 32u + waves * (RT_Q_CAND_CAP * 128u + 48u * P + RT_Q_WORDS * 256u);
+        lds = queue_lds(L.ulist_cap);
         // Who holds the open pixel units: each wavefront two of its own (rt_render_queue), or the workgroup a pool of
         // them from which all its wavefronts take camera rays (rt_render_pool).  The pool costs about 22 more
         // instructions per batch and trip (level on the 4K book frame, 3 % slower on the 8K mirror hall), but no wavefront

@@ -414,59 +414,75 @@ RT_DEV void scan_primary(const float4* geo0, const uint16_t* map, const Tile& ti
 
 // The camera rays of one pixel unit see few spheres, and all of its rays nearly the same ones (16 pixels x some
 // hundred samples, each ray within half a pixel of its pixel's centre).  So the scan over the whole list is done once
-// per UNIT instead of once per 64 rays: unit_list runs scan_primary's test with the image coordinates replaced by
-// whichever corner of the unit's footprint maximises the sphere's dq, and with an upper bound of iLs for the
-// footprint; the spheres that pass -- a superset of what any ray of the unit can list -- are copied, terms and index,
-// to a short list in LDS, lowest index first, and the unit's camera-ray batches scan that list instead of the scene
-// (scan_primary with the list's terms and index map).  Nothing changes in what the exact test sees, except that it sees it sooner.
-//   footprint: fx in [x0 - 1/2, x0 + w], fy in [y0 - 1/2, y0 + h] (sample_ray: pixel + jitter in [-1/2, 1/2), or the grid
-//   sampler's [0, 1)); fx*, fy* = the upper end where the sphere's A (B) is positive, the lower end otherwise.
-//   dq: fl(fx A + fl(fy B + C)) is monotone in fx A and in fy B (products exact, roundings monotone), so
-//   dq(fx*, fy*) >= dq(fx, fy) for every ray of the unit, also after the clamp.
-//   iLs: every ray's direction is within reach = (w + 1/2)/2 |du| + (h + 1/2)/2 |dv| of the direction through the
-//   footprint's centre, both as make_ray rounds them (RtLaunch.unit_reach adds twice the bound of those roundings), so
-//   |d| >= len_min = |d_centre| (1 - 2^-20) - reach and iLs(ray) = rsq(d.d)(1 + 2^-19) <= rsq(len_min^2 (1 - 2^-20))
-//   (1 + 2^-19)(1 + 2^-18) = iL, the 2^-18 covering rsq's 1-ulp error at both ends and the rounding of d.d.
-//   key = fma(dq*, iL, -sq) >= fma(dq, iLs, -sq) then (dq, iLs >= 0), and a product of non-negative factors plus -sq
-//   is never -0 unless the ray's is too: sign clear for the ray => sign clear for the unit.
-// No list (RT_UL_NONE; the batches scan the scene as before) if len_min <= 0 -- a degenerate camera, where rays may
-// have d.d = 0 and NaN keys --, or if more spheres pass than the list holds.
+// per UNIT instead of once per 64 rays: unit_list tests every sphere against the unit's bundle of rays, and the few
+// that can be hit by any of them -- about two per unit on the 485-sphere book scene at 4K, three on the 16,385-sphere
+// grid -- are copied, camera-ray terms and index, to a short list in LDS, lowest index first.  The unit's camera-ray
+// batches then run scan_primary over that list instead of over the scene.  Nothing changes in what the exact test
+// sees, except that it sees it sooner.
+//   The test is geometric and in double precision (the single-precision cone test of scan_primary cannot resolve a
+//   small far sphere from its neighbours: its slack for the rounding of the camera's directions is a slack on a cosine
+//   near 1).  With q = c - o and u the unit vector through the centre of the unit's footprint (fx in [x0 - 1/2, x0 + w],
+//   fy in [y0 - 1/2, y0 + h]: pixel + jitter in [-1/2, 1/2), or the grid sampler's [0, 1)), all from the camera's
+//   single-precision fields but exact to double rounding:
+//     dist^2 = |q|^2 - (u.q)^2                    squared distance from the centre to the central line
+//     r_eff^2 = r*r (1 + 2^-17) + 2^-18 |q|^2     the exact test accepts a ray with direction d only if the centre is
+//                                                 within r_eff of the ray's line (the inflations of scan_tile's
+//                                                 derivation, which cover the exact test's own roundings)
+//     s = reach / |d_centre|                      reach (RtLaunch.unit_reach) >= |d - d_centre| for every ray of the
+//                                                 unit as make_ray rounds it: (w + 1/2)/2 |du| + (h + 1/2)/2 |dv| + eta,
+//                                                 eta bounding make_ray's four roundings per component; so the sine of
+//                                                 the angle between a ray and the central line is at most s
+//   The centre's angle to a ray's line is at least its angle to the central line minus that angle, and sines of
+//   angles up to a right angle add at most: dist(ray) >= dist - |q| s.  A sphere is listed unless
+//     dist > r_eff + |q| (s + 2^-20)   or   u.q < -(r_eff + |q| (s + 2^-20))
+//   (the second: the centre lies behind every ray by more than r_eff, camera outside -- the exact test then has
+//   h = d.q <= 0 and ncc <= 0 and rejects; 2^-20 |q| covers its rounding of h).  Single-precision square roots
+//   (hardware, 1 ulp) are rounded up by 2^-20.  Anything that is not a number lists the sphere.
+// No list (RT_UL_NONE: the batches scan the scene as before) if reach >= |d_centre| -- a degenerate camera --, or if
+// more spheres pass than the list holds.
 #define RT_UL_NONE 0xffffffffu
-
-RT_DEV void ray_through(const RtCamera& cam, float fx, float fy, V3& o, V3& d);
 
 RT_DEV uint32_t uniform_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
 struct UnitList { float4* terms; uint16_t* idx; };             // RtLaunch.ulist_cap entries each, per wavefront or pool slot
 
-RT_DEV uint32_t unit_list(const float4* geo0, const RtCamera& cam, const RtLaunch& L, uint32_t x0, uint32_t y0,
-                          const UnitList& ul, uint32_t lane) {
-    const float fx_lo = (float)x0 - 0.5f, fx_hi = (float)(x0 + L.unit_w);
-    const float fy_lo = (float)y0 - 0.5f, fy_hi = (float)(y0 + L.unit_h);
-    V3 o, dc;
-    ray_through(cam, 0.5f * (fx_lo + fx_hi), 0.5f * (fy_lo + fy_hi), o, dc);
-    const float len_min = sqrtf(vdot(dc, dc)) * (1.0f - 0x1p-20f) - L.unit_reach;
-    if (!(len_min > 0.0f)) return RT_UL_NONE;                     // wave-uniform: every operand is
-    const float iL = filter_inv_len((len_min * len_min) * (1.0f - 0x1p-20f)) * (1.0f + 0x1p-18f);
+// exact: {c, r*r} per sphere (global memory); terms: the launch's camera-ray terms (LDS copy, or global memory where
+// the sphere list is streamed), copied for the listed spheres.
+RT_DEV uint32_t unit_list(const float4* __restrict__ exact, const float4* terms, const RtCamera& cam, const RtLaunch& L,
+                          uint32_t x0, uint32_t y0, const UnitList& ul, uint32_t lane) {
+    const double fxc = (double)x0 + 0.5 * ((double)L.unit_w - 0.5), fyc = (double)y0 + 0.5 * ((double)L.unit_h - 0.5);
+    const double ox = cam.center[0], oy = cam.center[1], oz = cam.center[2];
+    const double dx = ((double)cam.pixel00_loc[0] - ox) + (fxc * (double)cam.pixel_delta_u[0] + fyc * (double)cam.pixel_delta_v[0]);
+    const double dy = ((double)cam.pixel00_loc[1] - oy) + (fxc * (double)cam.pixel_delta_u[1] + fyc * (double)cam.pixel_delta_v[1]);
+    const double dz = ((double)cam.pixel00_loc[2] - oz) + (fxc * (double)cam.pixel_delta_u[2] + fyc * (double)cam.pixel_delta_v[2]);
+    const double len2 = dx * dx + dy * dy + dz * dz;
+    const float len_lo = __builtin_amdgcn_sqrtf((float)len2) * (1.0f - 0x1p-20f);
+    if (!(len_lo > L.unit_reach)) return RT_UL_NONE;              // wave-uniform: every operand is
+    const float s = L.unit_reach / len_lo * (1.0f + 0x1p-20f) + 0x1p-20f;
+    const double inv = 1.0 / sqrt(len2);
+    const double ux = dx * inv, uy = dy * inv, uz = dz * inv;
     uint32_t n = 0u;
     for (uint32_t first = 0u; first < L.n_padded; first += 64u) {
         const uint32_t i = first + lane;
         bool pass = false;
-        float4 t = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         if (i < L.n_padded) {
-            t = geo0[i];
-            const float fxs = (__float_as_uint(t.x) >> 31) ? fx_lo : fx_hi;
-            const float fys = (__float_as_uint(t.y) >> 31) ? fy_lo : fy_hi;
-            const float dq = __builtin_amdgcn_fmed3f(fmaf(fxs, t.x, fmaf(fys, t.y, t.z)), 0.0f, 1.0f);
-            const float key = fmaf(dq, iL, -t.w);
-            pass = (__float_as_uint(key) >> 31) == 0u;
+            const float4 e = exact[i];
+            const double qx = (double)e.x - ox, qy = (double)e.y - oy, qz = (double)e.z - oz;
+            const double qq = qx * qx + qy * qy + qz * qz;
+            const double t = ux * qx + uy * qy + uz * qz;
+            const double dist2 = qq - t * t;
+            const float qqf = (float)qq * (1.0f + 0x1p-20f);
+            const float r_eff = __builtin_amdgcn_sqrtf(fmaf(e.w, 1.0f + 0x1p-17f, 0x1p-18f * qqf) * (1.0f + 0x1p-20f)) * (1.0f + 0x1p-20f);
+            const float q_len = __builtin_amdgcn_sqrtf(qqf) * (1.0f + 0x1p-20f);
+            const double bound = (double)(fmaf(q_len, s, r_eff) * (1.0f + 0x1p-20f));
+            pass = !(dist2 > bound * bound) && !(t < -bound) && e.w != -INFINITY;   // (r*r = -inf: padding)
         }
         const unsigned long long m = __ballot(pass);
         const uint32_t cnt = (uint32_t)__popcll(m);
         if (n + cnt > L.ulist_cap) return RT_UL_NONE;
         if (pass) {
             const uint32_t r = n + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-            ul.terms[r] = t;
+            ul.terms[r] = terms[i];
             ul.idx[r] = (uint16_t)i;
         }
         n += cnt;
@@ -1234,7 +1250,7 @@ RT_DEV void render_queue_body(const Scene& sc, uint32_t* __restrict__ rgba, floa
                         next_samp = 0u;
                         if (cur) u1 = open_unit(L, unit, n_samp); else u0 = open_unit(L, unit, n_samp);
                         if (n_samp == 0u) continue;
-                        ul_k = L.ulist_cap ? uniform_u32(unit_list(geo0, cam, L, cur ? u1.x0 : u0.x0, cur ? u1.y0 : u0.y0, ul, lane)) : RT_UL_NONE;
+                        ul_k = L.ulist_cap ? uniform_u32(unit_list(sc.exact, geo0, cam, L, cur ? u1.x0 : u0.x0, cur ? u1.y0 : u0.y0, ul, lane)) : RT_UL_NONE;
                     }
                 }
             }
@@ -1326,7 +1342,7 @@ RT_DEV UnitList pool_list(const RtLaunch& L, uint32_t slot) {
 }
 
 RT_DEV bool pool_open(const RtLaunch& L, uint32_t* slots, uint32_t* ctl, uint32_t* __restrict__ work, uint32_t n_samp,
-                      uint32_t lane, uint32_t ahead, const RtCamera& cam, bool& drained) {
+                      uint32_t lane, uint32_t ahead, const RtCamera& cam, const float4* __restrict__ exact, bool& drained) {
     uint32_t lock = 1u;
     if (lane == 0u) lock = atomicCAS(&ctl[1], 0u, 1u);
     if (uniform_u32(lock) != 0u) return false;                    // somebody is opening one
@@ -1359,7 +1375,7 @@ RT_DEV bool pool_open(const RtLaunch& L, uint32_t* slots, uint32_t* ctl, uint32_
             } else {
                 const Slot u = open_unit(L, unit, n_samp);
                 // the free slot's list is nobody's: written here, published with the slot below
-                const uint32_t ul_k = L.ulist_cap ? uniform_u32(unit_list(rt_lds + L.n_padded, cam, L, u.x0, u.y0, pool_list(L, f), lane)) : RT_UL_NONE;
+                const uint32_t ul_k = L.ulist_cap ? uniform_u32(unit_list(exact, rt_lds + L.n_padded, cam, L, u.x0, u.y0, pool_list(L, f), lane)) : RT_UL_NONE;
                 if (lane == 0u) {
                     slots[f * 8u + 6u] = ul_k;
                     slots[f * 8u + 0u] = u.x0;
@@ -1383,7 +1399,7 @@ RT_DEV bool pool_open(const RtLaunch& L, uint32_t* slots, uint32_t* ctl, uint32_
 // still held by unfinished paths, or the launch's counter has run out: `drained`).
 // ahead_at: the wavefront whose batch contains this sample of a unit opens the next unit (pool_open).
 RT_DEV bool pool_next_batch(const RtLaunch& L, uint32_t* slots, uint32_t* ctl, uint32_t* __restrict__ work, uint32_t n_samp,
-                            uint32_t ahead_at, uint32_t lane, const RtCamera& cam, uint32_t& hint, uint32_t& slot, uint32_t& first,
+                            uint32_t ahead_at, uint32_t lane, const RtCamera& cam, const float4* __restrict__ exact, uint32_t& hint, uint32_t& slot, uint32_t& first,
                             uint4& head, bool& drained) {
     bool got = false;
     // The slot this wavefront last took a batch from is tried first.  A unit that still has untraced samples is good
@@ -1420,11 +1436,11 @@ RT_DEV bool pool_next_batch(const RtLaunch& L, uint32_t* slots, uint32_t* ctl, u
             }
         }
         // the current unit is used up (or there is none yet): open the next one, if nobody else is at it
-        if (!pool_open(L, slots, ctl, work, n_samp, lane, POOL_NONE, cam, drained)) return false;
+        if (!pool_open(L, slots, ctl, work, n_samp, lane, POOL_NONE, cam, exact, drained)) return false;
     }
     if (got && ahead_at >= first && ahead_at < first + 64u) {
         bool unused = false;
-        (void)pool_open(L, slots, ctl, work, n_samp, lane, slot, cam, unused);
+        (void)pool_open(L, slots, ctl, work, n_samp, lane, slot, cam, exact, unused);
     }
     return got;
 }
@@ -1539,7 +1555,7 @@ RT_DEV void render_pool_body(const Scene& sc, uint32_t* __restrict__ rgba, float
         if (want != 0ull && !drained) {
             uint32_t sl = 0u, first = 0u;
             uint4 head = make_uint4(0u, 0u, 0u, 0u);
-            if (pool_next_batch(L, slots, ctl, work, n_samp, ahead_at, lane, cam, hint, sl, first, head, drained)) {
+            if (pool_next_batch(L, slots, ctl, work, n_samp, ahead_at, lane, cam, sc.exact, hint, sl, first, head, drained)) {
                 Slot u;
                 u.open = true; u.left = 0u;
                 u.x0 = uniform_u32(head.x);
@@ -1642,13 +1658,20 @@ RT_DEV void render_queue_stream_body(const Scene& sc, uint32_t* __restrict__ rgb
 
     float4* geo = rt_lds;
     float4* geo0 = rt_lds + S;
-    char* mine = reinterpret_cast<char*>(geo0 + S) + wave * (RT_Q_CAND_CAP * 128u + 48u * P + RT_Q_WORDS * 256u);
+    char* mine = reinterpret_cast<char*>(geo0 + S) + wave * (RT_Q_CAND_CAP * 128u + 48u * P + RT_Q_WORDS * 256u + RT_UL_BYTES(L.ulist_cap));
     Cand cand;
     cand.col = reinterpret_cast<uint16_t*>(mine) + lane;
     cand.n = 0u;
     cand.cap = RT_Q_CAND_CAP;
     unsigned long long* accum = reinterpret_cast<unsigned long long*>(mine + RT_Q_CAND_CAP * 128u);
     uint32_t* q = reinterpret_cast<uint32_t*>(mine + RT_Q_CAND_CAP * 128u + 48u * P);
+    // the list of the unit whose camera rays are being traced (unit_list, from the camera-ray terms in global memory):
+    // with it a camera-ray batch needs no sweep over the tiles and is traced between the workgroup's rounds
+    UnitList ul;
+    ul.terms = reinterpret_cast<float4*>(mine + RT_Q_CAND_CAP * 128u + 48u * P + RT_Q_WORDS * 256u);
+    ul.idx = reinterpret_cast<uint16_t*>(ul.terms + L.ulist_cap);
+    uint32_t ul_k = RT_UL_NONE;
+    const Tile whole = {geo, sc.exact};                           // exact-test data of the whole list, by sphere index
     for (uint32_t k = lane; k < 6u * P; k += 64u) accum[k] = 0ull;
     float4* fold = FOLD ? fold_all + (size_t)(blockIdx.x * (blockDim.x >> 6) + wave) * (2u * P * (size_t)L.samples_per_pixel) : nullptr;
     const float4* fold1 = FOLD ? fold + (size_t)P * L.samples_per_pixel : nullptr;
@@ -1668,38 +1691,46 @@ RT_DEV void render_queue_stream_body(const Scene& sc, uint32_t* __restrict__ rgb
     float band = 0.0f;
 
     for (;;) {
-        if (u0.open && u0.left == 0u) { write_unit(L, u0, accum, lane, true, rgba, linear, fold); u0.open = false; }
-        if (u1.open && u1.left == 0u) { write_unit(L, u1, accum + 3u * P, lane, true, rgba, linear, fold1); u1.open = false; }
-
-        // lanes without a path take queued rays
-        unsigned long long want = __ballot(need);
-        if (want != 0ull && q_head < q_count) {
-            const uint32_t j = q_head + __builtin_amdgcn_mbcnt_hi((uint32_t)(want >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)want, 0u));
-            if (need && j < q_count) {
-                take_queued(sc, L, q, j, u0, u1, p, s, pixel, pixslot, band);
-                need = false;
-                active = true;
-            }
-            const uint32_t asked = (uint32_t)__popcll(want);
-            q_head += asked < q_count - q_head ? asked : q_count - q_head;
-            want = __ballot(need);
-        }
-        // a lane still without work and nothing queued: this round goes to the next camera rays
+        // Between the workgroup's rounds: lanes without a path take queued rays; while some are still without one and
+        // the queue is empty, the next camera rays of a unit WITH a list are traced on the spot (no tiles needed).  A
+        // unit without a list has its camera rays traced in a round of their own (primary).
         bool primary = false;
-        if (want != 0ull && q_head == q_count) {
-            if (next_samp >= n_samp && !drained && !(cur ? u0.open : u1.open)) {
+        unsigned long long want;
+        for (;;) {
+            if (u0.open && u0.left == 0u) { write_unit(L, u0, accum, lane, true, rgba, linear, fold); u0.open = false; }
+            if (u1.open && u1.left == 0u) { write_unit(L, u1, accum + 3u * P, lane, true, rgba, linear, fold1); u1.open = false; }
+            want = __ballot(need);
+            if (want != 0ull && q_head < q_count) {
+                const uint32_t j = q_head + __builtin_amdgcn_mbcnt_hi((uint32_t)(want >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)want, 0u));
+                if (need && j < q_count) {
+                    take_queued(sc, L, q, j, u0, u1, p, s, pixel, pixslot, band);
+                    need = false;
+                    active = true;
+                }
+                const uint32_t asked = (uint32_t)__popcll(want);
+                q_head += asked < q_count - q_head ? asked : q_count - q_head;
+                want = __ballot(need);
+            }
+            if (want == 0ull || q_head != q_count) break;
+            if (next_samp >= n_samp) {
+                if (drained || (cur ? u0.open : u1.open)) break;
                 uint32_t unit = 0u;
                 if (lane == 0u) unit = atomicAdd(work, 1u);
                 unit = (uint32_t)__builtin_amdgcn_readfirstlane((int)unit);
-                if (unit >= L.n_units) {
-                    drained = true;
-                } else {
-                    cur ^= 1u;
-                    next_samp = 0u;
-                    if (cur) u1 = open_unit(L, unit, n_samp); else u0 = open_unit(L, unit, n_samp);
-                }
+                if (unit >= L.n_units) { drained = true; break; }
+                cur ^= 1u;
+                next_samp = 0u;
+                if (cur) u1 = open_unit(L, unit, n_samp); else u0 = open_unit(L, unit, n_samp);
+                if (n_samp == 0u) continue;
+                ul_k = L.ulist_cap ? uniform_u32(unit_list(sc.exact, camterms, cam, L, cur ? u1.x0 : u0.x0, cur ? u1.y0 : u0.y0, ul, lane)) : RT_UL_NONE;
             }
-            primary = next_samp < n_samp;
+            if (ul_k == RT_UL_NONE) { primary = true; break; }
+            uint32_t completed = 0u;
+            primary_batch(sc, whole, geo0, cam, L, seed, T, cur ? u1 : u0, cur, next_samp, n_samp, accum, fold, q, cand, ul, ul_k,
+                          q_count, completed, nseg, st);
+            q_head = 0u;
+            next_samp = next_samp + 64u < n_samp ? next_samp + 64u : n_samp;
+            if (cur) u1.left -= completed; else u0.left -= completed;
         }
         const bool more = active || q_head < q_count || !drained || next_samp < n_samp || u0.open || u1.open;
         if (!__syncthreads_or(more ? 1 : 0)) break;
