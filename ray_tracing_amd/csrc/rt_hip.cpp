@@ -345,7 +345,7 @@ RtLaunch make_launch(const rt_ctx* c, const RtCamera* cam, const RtParams* p, ui
             L.ulist_cap = 16u;
         }
     }
-    if (const char* e = std::getenv("RT_EXP_ULIST_CAP")) {                       // timing experiments only: 0 .. 16
+    if (const char* e = std::getenv("RT_EXP_ULIST_CAP")) {                       // timing experiments and tests only: 0 .. 16
         const unsigned v = (unsigned)std::atoi(e);
         if (v < L.ulist_cap) L.ulist_cap = v & ~1u;
     }

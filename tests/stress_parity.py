@@ -1,6 +1,7 @@
 """Randomised GPU-vs-checker stress run, beyond what the test-suite holds: N seeded scenes built to strain the scan
 filters (spheres behind rays, nested and overlapping spheres so that bounce rays start inside other spheres, cameras
-inside glass, a huge ground, radii over four decades, scenes far from the origin, lists beyond one LDS tile), every
+inside glass, a huge ground, radii over four decades, scenes far from the origin, lists beyond one LDS tile, frames
+from 16 to 360 pixels wide), every
 sample its own work item under both schedulers plus the fold, each compared bit for bit (linear radiance, RGBA8,
 segment count) with the CPU checker (oracle/, test infrastructure).
     python tests/stress_parity.py [N=200] [first_seed=0]
@@ -45,12 +46,13 @@ for case in range(first, first + n_cases):
     sp["albedo"] = rng.uniform(0.3, 1.0, (n, 3)).astype(np.float32)
     fuzz = np.where(rng.random(n) < 0.5, 0.0, rng.uniform(0.0, 1.0, n))      # half of the metals are perfect mirrors
     sp["param"] = np.where(sp["material"] == 3, rng.choice([1.5, 1.0 / 1.5, 2.4], n), fuzz).astype(np.float32)
-    width = int(rng.integers(16, 80))
+    # (every third frame wide enough for the pixel units' sphere lists to be short, i.e. used)
+    width = int(rng.integers(16, 80)) if case % 3 else int(rng.integers(160, 360))
     inside = kind in (2, 4)                                                  # camera inside the cloud / inside a shell
     lookfrom = shift + (rng.normal(0, 0.3 * extent, 3) if inside else rng.normal(0, 1, 3) * extent * rng.uniform(3, 8))
     cam = rt.Camera.look_at(float(rng.choice([16 / 9, 1.0])), width, float(rng.uniform(15, 110)),
                             tuple(lookfrom), tuple(shift + rng.normal(0, 0.2 * extent, 3)))
-    spp = int(rng.integers(2, 7))
+    spp = int(rng.integers(2, 7)) if case % 3 else int(rng.integers(4, 9))
     depth = int(rng.choice([2, 5, 12, 40]))
     hip.upload_scene(sp)
     ocam = oracle.camera_f32_from_rt(cam.block)

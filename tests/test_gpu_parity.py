@@ -615,6 +615,38 @@ def test_unit_size_does_not_change_the_image(rt, hip):
         assert np.array_equal(f["linear"], frames[0]["linear"]) and f["rays"] == frames[0]["rays"]
 
 
+def test_pixel_unit_sphere_lists_change_nothing_but_the_time(rt, hip, monkeypatch):
+    """Camera-ray batches scan their pixel unit's short sphere list instead of the scene (unit_list, rt_kernels.hip).
+    With the lists switched off (RT_EXP_ULIST_CAP=0, read by every launch) the frames are the same bit for bit -- both
+    schedulers, the fold, and the kernel that streams a 1,601-sphere list -- and the book scene takes measurably longer
+    (the lists are in use: a frame's camera rays cost four operations per sphere and ray without them)."""
+    book = rt.scene_book1_final(1)
+    grid = rt.scene_grid(2, 40)
+    cases = [(book, rt.Camera.look_at(16.0 / 9.0, 480, 20.0, (13.0, 2.0, 3.0), (0.0, 0.0, 0.0)), 128, 12),   # (16x1 units on either scheduler)
+             (grid, rt.Camera.look_at(16.0 / 9.0, 480, 40.0, (0.0, 12.0, 30.0), (0.0, 0.0, 0.0)), 8, 6)]
+    for sp, cam, spp, depth in cases:
+        hip.upload_scene(sp)
+        for chunk, scheds in ((1, ("wave", "pool")), (0, ("auto",))):
+            p = rt.DeviceGUI(samples_per_pixel=spp, max_depth=depth, seed=11, sample_chunk=chunk)
+            for sched in scheds:
+                hip.debug_schedule(scheduler=sched)
+                frames, ms = [], []
+                for cap in ("16", "0"):
+                    monkeypatch.setenv("RT_EXP_ULIST_CAP", cap)
+                    best = float("inf")
+                    for _ in range(2):
+                        f = hip.render(cam, p, linear=True)
+                        best = min(best, f["kernel_ms"])
+                    frames.append(f)
+                    ms.append(best)
+                monkeypatch.delenv("RT_EXP_ULIST_CAP")
+                hip.debug_schedule()
+                assert np.array_equal(frames[0]["linear"].view(np.uint32), frames[1]["linear"].view(np.uint32))
+                assert np.array_equal(frames[0]["rgba"], frames[1]["rgba"]) and frames[0]["rays"] == frames[1]["rays"]
+                if sp is book and chunk == 1:
+                    assert ms[0] < 0.95 * ms[1], (sched, ms)
+
+
 def test_scheduler_is_chosen_by_launch_size_and_does_not_change_the_image(rt, hip):
     """With every sample its own item the library pools the pixel units per workgroup on short launches (an estimate of the
     launch's work per resident wavefront, rt_hip.cpp make_launch) and leaves them with the wavefronts on larger ones (the crossover itself is timed on

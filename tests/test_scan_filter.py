@@ -22,6 +22,10 @@ d = P0 + fx du + fy dv, so with q = c - o the condition becomes |d.q| / |d| >= s
   with A, B, C, sq all times rho = 2^-k, rho * 2 max M < 1 (M = |C| + (W+1)|A| + (H+1)|B| bounds |dq|): the clamp's lower end
   drops spheres behind the camera ray unless the camera is inside them; the bar is accept_exact's full precondition.
 The direction the exact test sees is make_ray's rounded one; the filter works from fx, fy.
+Pixel units (unit_list): the spheres a unit's camera-ray batches scan are chosen once per unit by a geometric test in
+double precision -- centre within r_eff + |q| (s + 2^-20) of the line through the centre of the unit's footprint, and
+not behind it by more than that (r_eff^2 = r*r (1+2^-17) + 2^-18 |q|^2; s = reach / |d_centre|, reach from the launcher,
+make_launch).  Every sphere accept_exact can accept for any ray of the unit must be listed.
 Here both are evaluated in numpy with float32 fma emulated through float64 (products of two float32 are
 exact in float64), on random and adversarial ray/sphere pairs."""
 import numpy as np
@@ -335,6 +339,96 @@ def test_camera_ray_filter_camera_inside_on_surfaces_and_the_ground_sphere():
         r = np.full(n, 1000.0)
         c = o64 + np.stack([rng.uniform(-5, 5, n), -1000.0 - rng.uniform(1e-4, 3.0, n), rng.uniform(-5, 5, n)])
         check_camera(cam, fx, fy, list(c), r, f"{name}, ground sphere")
+
+
+def unit_reach(cam, uw, uh):
+    """make_launch (rt_hip.cpp): (w + 1/2)/2 |du| + (h + 1/2)/2 |dv| + eta, rounded up to single precision."""
+    o, p00, du, dv, W, H = [x.astype(np.float64) if isinstance(x, np.ndarray) else x for x in _cam_arrays(cam)]
+    W1, H1 = W + 1.0, H + 1.0
+    eta = np.sqrt(sum((2.0 ** -24 * (abs(p00[k]) + abs(p00[k] - o[k]) + 3.0 * W1 * abs(du[k]) + 4.0 * H1 * abs(dv[k]))) ** 2 for k in range(3)))
+    reach = (0.5 * (uw + 0.5) * np.linalg.norm(du) + 0.5 * (uh + 0.5) * np.linalg.norm(dv) + eta) * (1.0 + 2.0 ** -20)
+    return np.nextafter(f32(reach), f32(np.inf))
+
+
+def unit_listed(cam, x0, y0, uw, uh, c, rr):
+    """unit_list of the kernel for the unit at (x0, y0) (arrays: one unit and one sphere per element), operation for
+    operation; the hardware's 1-ulp square roots are modelled 2 ulps too SMALL where a larger value lists more (the
+    model is then stricter than the kernel).  Returns None where the kernel builds no list."""
+    o, p00, du, dv, W, H = [x.astype(np.float64) if isinstance(x, np.ndarray) else x for x in _cam_arrays(cam)]
+    reach = unit_reach(cam, uw, uh)
+    fxc = x0.astype(np.float64) + 0.5 * (uw - 0.5)
+    fyc = y0.astype(np.float64) + 0.5 * (uh - 0.5)
+    d = [(p00[k] - o[k]) + (fxc * du[k] + fyc * dv[k]) for k in range(3)]
+    len2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2]
+    down = lambda x: np.nextafter(np.nextafter(x, f32(0.0)), f32(0.0))
+    len_lo = (np.nextafter(np.sqrt(len2.astype(f32)), f32(np.inf)) * f32(1.0 - 2.0 ** -20)).astype(f32)   # (larger is the risky side here)
+    assert (len_lo > reach).all()
+    s_ = ((reach / len_lo).astype(f32) * f32(1.0 + 2.0 ** -20)).astype(f32) + f32(2.0 ** -20)
+    inv = 1.0 / np.sqrt(len2)
+    u = [d[k] * inv for k in range(3)]
+    q = [c[k].astype(np.float64) - o[k] for k in range(3)]
+    qq = q[0] * q[0] + q[1] * q[1] + q[2] * q[2]
+    t = u[0] * q[0] + u[1] * q[1] + u[2] * q[2]
+    dist2 = qq - t * t
+    qqf = (qq.astype(f32) * f32(1.0 + 2.0 ** -20)).astype(f32)
+    val = (fma(rr, np.full_like(rr, f32(1.0 + 2.0 ** -17)), (f32(2.0 ** -18) * qqf).astype(f32)) * f32(1.0 + 2.0 ** -20)).astype(f32)
+    r_eff = (down(np.sqrt(val)) * f32(1.0 + 2.0 ** -20)).astype(f32)
+    q_len = (down(np.sqrt(qqf)) * f32(1.0 + 2.0 ** -20)).astype(f32)
+    bound = (fma(q_len, s_.astype(f32), r_eff) * f32(1.0 + 2.0 ** -20)).astype(f32).astype(np.float64)
+    return ~(dist2 > bound * bound) & ~(t < -bound)
+
+
+def test_unit_lists_hold_every_sphere_a_ray_of_the_unit_can_hit():
+    """Rays anywhere in a unit's footprint (corners and edges included) against spheres that graze them within a few
+    ulps, are hit squarely, are missed, contain the camera or lie behind it: what accept_exact can accept is on the
+    unit's list -- for the unit shapes the launcher uses, on every benchmark camera and the hostile ones -- and the
+    lists stay short: spheres that a ray misses by more than the unit's width and their own radius are not listed."""
+    rng = np.random.default_rng(9)
+    n = 300_000
+    for name, cam in _cameras().items():
+        o_, p00, du, dv, W, H = _cam_arrays(cam)
+        for uw, uh in ((16, 1), (4, 1), (16, 4), (8, 8)):
+            x0 = (rng.integers(0, max(1, W // uw), n) * uw).astype(np.int64)
+            y0 = (rng.integers(0, max(1, H // uh), n) * uh).astype(np.int64)
+            # image coordinates as sample_ray makes them: pixel + [-1/2, 1/2) or the grid sampler's [0, 1); a third on the footprint's rim
+            fx = x0 + rng.integers(0, uw, n) + rng.uniform(-0.5, 1.0, n)
+            fy = y0 + rng.integers(0, uh, n) + rng.uniform(-0.5, 1.0, n)
+            rim = rng.random(n) < 0.33
+            fx = np.where(rim, np.where(rng.random(n) < 0.5, x0 - 0.5, x0 + uw - 2.0 ** -10), fx)
+            fy = np.where(rim, np.where(rng.random(n) < 0.5, y0 - 0.5, y0 + uh - 2.0 ** -10), fy)
+            fx, fy = fx.astype(f32), fy.astype(f32)
+            o, d = camera_ray(cam, fx, fy)
+            d64 = np.stack([x.astype(np.float64) for x in d])
+            dl = np.linalg.norm(d64, axis=0)
+            u = d64 / dl
+            perp = np.cross(u.T, unit(rng, n).T).T
+            perp /= np.linalg.norm(perp, axis=0)
+            scale = max(1.0, float(np.linalg.norm(p00.astype(np.float64) - o_.astype(np.float64))))
+            r = rng.uniform(0.05, 2.0, n) * rng.choice([1.0, 1.0, 30.0], n)
+            dist = rng.uniform(0.2, 80.0, n) * scale * rng.choice([1.0, -1.0], n, p=[0.9, 0.1])
+            for kind, miss in (("grazing", 1.0 + rng.uniform(-4e-7, 4e-7, n)), ("random", rng.uniform(0.0, 1.5, n)),
+                               ("camera inside", None)):
+                if miss is None:
+                    r2 = rng.uniform(0.5, 30.0, n)
+                    c = o_.astype(np.float64)[:, None] + unit(rng, n) * r2 * rng.uniform(0.0, 1.0, n)
+                    rr = (r2.astype(f32) * r2.astype(f32)).astype(f32)
+                else:
+                    c = o_.astype(np.float64)[:, None] + u * dist + perp * r * miss
+                    rr = (r.astype(f32) * r.astype(f32)).astype(f32)
+                c32 = [x.astype(f32) for x in c]
+                _, a, h, ncc, disc = terms(o, d, c32, rr)
+                accepted = (disc >= 0) & ((h > 0) | (ncc > 0))
+                listed = unit_listed(cam, x0, y0, uw, uh, c32, rr)
+                label = f"{name}, {uw}x{uh} units, {kind}"
+                assert accepted.sum() > 0, label
+                dropped = accepted & ~listed
+                assert not dropped.any(), f"{label}: {dropped.sum()} spheres a ray of the unit can hit are not on the unit's list"
+                if kind == "random" and "far" not in name:
+                    # a sphere missed by three radii and thrice the footprint's width at its depth is not listed
+                    foot = np.abs(dist) * float(unit_reach(cam, uw, uh)) / dl
+                    clear = (miss > 1.4) & (dist > 0) & (0.4 * r > 3.0 * foot) & (r > 2.0 ** -7 * np.abs(dist))   # (r_eff adds 2^-9 |q| in quadrature)
+                    if clear.sum() > 100:
+                        assert listed[clear].mean() < 0.01, (label, listed[clear].mean())
 
 
 def test_half_line_filter_on_bounce_rays_between_spheres():
