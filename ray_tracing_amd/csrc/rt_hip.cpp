@@ -39,7 +39,7 @@ struct rt_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipModule_t module = nullptr;
-    hipFunction_t f_render = nullptr, f_render_queue = nullptr, f_render_queue_fold = nullptr, f_render_queue_stream_fold = nullptr, f_render_stream = nullptr, f_render_queue_stream = nullptr, f_hits = nullptr, f_random = nullptr, f_assemble = nullptr, f_camera_terms = nullptr, f_render_pool = nullptr, f_render_pool_fold = nullptr;
+    hipFunction_t f_render = nullptr, f_render_queue = nullptr, f_render_queue_fold = nullptr, f_render_queue_stream_fold = nullptr, f_render_stream = nullptr, f_render_queue_stream = nullptr, f_hits = nullptr, f_random = nullptr, f_assemble = nullptr, f_camera_terms = nullptr, f_render_pool = nullptr, f_render_pool_fold = nullptr, f_render_pool_plain = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     void *d_geom = nullptr, *d_exact = nullptr, *d_shade = nullptr, *d_mat = nullptr;
     void* d_camterms = nullptr;         // per sphere {A, B, C, sq} of the camera-ray scan, rewritten by every launch (rt_camera_terms)
@@ -162,6 +162,7 @@ int load_image(rt_ctx* c, const void* image) {
     c->module = m;
     if (hipModuleGetFunction(&c->f_render_pool, m, "rt_render_pool") != hipSuccess) { c->f_render_pool = nullptr; (void)hipGetLastError(); }
     if (hipModuleGetFunction(&c->f_render_pool_fold, m, "rt_render_pool_fold") != hipSuccess) { c->f_render_pool_fold = nullptr; (void)hipGetLastError(); }
+    if (hipModuleGetFunction(&c->f_render_pool_plain, m, "rt_render_pool_plain") != hipSuccess) { c->f_render_pool_plain = nullptr; (void)hipGetLastError(); }
     c->f_render_queue_fold = fqf; c->f_render_queue_stream_fold = fqsf; c->f_render = fr; c->f_render_queue = fq; c->f_render_queue_stream = fqs; c->f_render_stream = fs; c->f_hits = fh; c->f_random = fx; c->f_assemble = fa; c->f_camera_terms = fct;
     return 0;
 }
@@ -273,17 +274,18 @@ RtLaunch make_launch(const rt_ctx* c, const RtCamera* cam, const RtParams* p, ui
         };
         // Short launches run with the units pooled per workgroup (rt_render_pool, see launch_render): the end of the launch,
         // when the wavefronts run out of units one by one, then costs little -- whole workgroups finish the last units --
-        // and the units can have their full size.  In steady state the pooled kernel is 6-8 % behind (more wave-uniform
-        // state than there are scalar registers, and its bookkeeping per camera-ray batch weighs more since the units'
-        // sphere lists shortened the batches).  The crossover is a launch length: about 95 ms of kernel time, estimated
-        // here as samples per resident wavefront (24 per compute unit) x (spheres + 56) < 44 M, a segment's cost being
-        // 9 operations per sphere and some 500 beside the scan.  Measured with 16x1 units (kernel ms, per-wavefront /
-        // pooled; same box): book scene 4K at 500 spp, depth 50 (486 spheres): whole frame = 675 k samples per wavefront
-        // 744 / 790, a quarter 185 / 199, an eighth (84 k x 542 = 46 M) 99.5 / 99.7, a sixteenth 52.4 / 52.5; mirror hall
-        // 8K at 256 spp, depth 100 (66 spheres): whole frame = 1.38 M samples per wavefront 344 / 371, half 177 / 186, a
-        // quarter (345 k x 122 = 42 M) 96.0 / 93.6, an eighth 49.2 / 47.5, a sixteenth 24.5 / 23.9.
+        // and the units can have their full size.  In steady state the pooled kernel is behind, 1 % on the book scene and
+        // 9 % in the mirror hall (its bookkeeping per camera-ray batch weighs more since the units' sphere lists shortened
+        // the batches, and it holds more wave-uniform state than there are scalar registers).  The crossover is a launch
+        // length, about 120 ms of kernel time, estimated here as samples per resident wavefront (24 per compute unit)
+        // x (spheres + 56) < 60 M, a segment's cost being 9 operations per sphere and some 500 beside the scan.
+        // Measured with 16x1 units (kernel ms, per-wavefront / pooled; one box): book scene 4K at 500 spp, depth 50 (486
+        // spheres): whole frame = 675 k samples per wavefront 760 / 766, half 380 / 384, a quarter (169 k x 542 = 91 M)
+        // 190 / 194, an eighth (46 M) 97.9 / 96.9, a sixteenth 53.0 / 50.3; mirror hall 8K at 256 spp, depth 100 (66
+        // spheres): whole frame = 1.38 M samples per wavefront 344 / 376, half (691 k x 122 = 84 M) 177 / 189, a quarter
+        // (42 M) 97.2 / 95.0, an eighth 48.5 / 48.0, a sixteenth 24.6 / 24.3.
         const uint64_t launch_samples = (uint64_t)cam->image_width * rows_local * spp;
-        const bool small_launch = launch_samples * (c->n_padded + 56u) < resident * 44000000ull;
+        const bool small_launch = launch_samples * (c->n_padded + 56u) < resident * 60000000ull;
         const bool pool_able = L.chunk == 1u && L.n_chunks > 1u && queue_kernel_fits(c, cam, spp) && p->max_depth > 0u &&
                                c->n_padded <= RT_TILE_SPHERES && (fold ? c->f_render_pool_fold : c->f_render_pool) != nullptr &&
                                c->dbg_scheduler != RT_SCHED_WAVE;
@@ -424,6 +426,10 @@ int launch_render(rt_ctx* c, const RtCamera* cam, const RtParams* p, RtLaunch L,
         if (L.pool_slots != 0u) {
             f = L.fold ? c->f_render_pool_fold : c->f_render_pool;
             c->last_kernel = L.fold ? "rt_render_pool_fold" : "rt_render_pool";
+            if (!L.fold && L.ulist_cap == 0u && c->f_render_pool_plain) {   // the build without the units' sphere lists
+                f = c->f_render_pool_plain;
+                c->last_kernel = "rt_render_pool_plain";
+            }
             // as many open units as the wavefronts would hold between them, so the same LDS: slot headers, the
             // control words, the slots' accumulators, and per wavefront the candidate lists and the ray queue
             L.pool_slots = 2u * waves;

@@ -1106,6 +1106,8 @@ RT_DEV uint32_t queue_rays(uint32_t* q, bool cont, const Path& p, uint32_t s, ui
 // Traces and shades the camera rays of samples first .. first+63 of unit `u` (sample i: pixel i % P, sample
 // number i / P).  Called by the whole wavefront.  Finished samples (miss, depth limit, pixel outside the
 // image) are counted in `completed`; the others leave a ray in the queue, packed from slot 0 (`queued`).
+// LISTS = false: a build of the caller without the units' sphere lists (ul, ul_k unused).
+template <bool LISTS>
 RT_DEV void primary_batch(const Scene& sc, const Tile& tile, const float4* __restrict__ geo0, const RtCamera& cam,
                           const RtLaunch& L, uint64_t seed, V3 T, const Slot& u, uint32_t slot, uint32_t first,
                           uint32_t n_samp, unsigned long long* acc, float4* fold, uint32_t* q, Cand& cand,
@@ -1135,7 +1137,7 @@ RT_DEV void primary_batch(const Scene& sc, const Tile& tile, const float4* __res
         b.idx = -1;
         st.lap(14);
         // ul_k (wave-uniform): entries of the unit's list, or RT_UL_NONE: the whole scene
-        const bool listed = ul_k != RT_UL_NONE;
+        const bool listed = LISTS && ul_k != RT_UL_NONE;
         const float4* terms = listed ? ul.terms : geo0;
         const uint16_t* map = listed ? ul.idx : nullptr;
         const uint32_t n_terms = listed ? ul_k : L.n_padded;
@@ -1256,8 +1258,8 @@ RT_DEV void render_queue_body(const Scene& sc, uint32_t* __restrict__ rgba, floa
             }
             if (can) {
                 uint32_t completed = 0u;
-                primary_batch(sc, tile, geo0, cam, L, seed, T, cur ? u1 : u0, cur, next_samp, n_samp,
-                              accum, fold, q, cand, ul, ul_k, q_count, completed, nseg, st);
+                primary_batch<true>(sc, tile, geo0, cam, L, seed, T, cur ? u1 : u0, cur, next_samp, n_samp,
+                                    accum, fold, q, cand, ul, ul_k, q_count, completed, nseg, st);
                 q_head = 0u;
                 next_samp = next_samp + 64u < n_samp ? next_samp + 64u : n_samp;
                 if (cur) u1.left -= completed; else u0.left -= completed;
@@ -1341,6 +1343,7 @@ RT_DEV UnitList pool_list(const RtLaunch& L, uint32_t slot) {
     return ul;
 }
 
+template <bool LISTS>
 RT_DEV bool pool_open(const RtLaunch& L, uint32_t* slots, uint32_t* ctl, uint32_t* __restrict__ work, uint32_t n_samp,
                       uint32_t lane, uint32_t ahead, const RtCamera& cam, const float4* __restrict__ exact, bool& drained) {
     uint32_t lock = 1u;
@@ -1375,7 +1378,8 @@ RT_DEV bool pool_open(const RtLaunch& L, uint32_t* slots, uint32_t* ctl, uint32_
             } else {
                 const Slot u = open_unit(L, unit, n_samp);
                 // the free slot's list is nobody's: written here, published with the slot below
-                const uint32_t ul_k = L.ulist_cap ? uniform_u32(unit_list(exact, rt_lds + L.n_padded, cam, L, u.x0, u.y0, pool_list(L, f), lane)) : RT_UL_NONE;
+                uint32_t ul_k = RT_UL_NONE;
+                if (LISTS && L.ulist_cap) ul_k = uniform_u32(unit_list(exact, rt_lds + L.n_padded, cam, L, u.x0, u.y0, pool_list(L, f), lane));
                 if (lane == 0u) {
                     slots[f * 8u + 6u] = ul_k;
                     slots[f * 8u + 0u] = u.x0;
@@ -1398,6 +1402,7 @@ RT_DEV bool pool_open(const RtLaunch& L, uint32_t* slots, uint32_t* ctl, uint32_
 // none to be had right now (the current unit is used up and another wavefront is opening the next one, every slot is
 // still held by unfinished paths, or the launch's counter has run out: `drained`).
 // ahead_at: the wavefront whose batch contains this sample of a unit opens the next unit (pool_open).
+template <bool LISTS>
 RT_DEV bool pool_next_batch(const RtLaunch& L, uint32_t* slots, uint32_t* ctl, uint32_t* __restrict__ work, uint32_t n_samp,
                             uint32_t ahead_at, uint32_t lane, const RtCamera& cam, const float4* __restrict__ exact, uint32_t& hint, uint32_t& slot, uint32_t& first,
                             uint4& head, bool& drained) {
@@ -1436,11 +1441,11 @@ RT_DEV bool pool_next_batch(const RtLaunch& L, uint32_t* slots, uint32_t* ctl, u
             }
         }
         // the current unit is used up (or there is none yet): open the next one, if nobody else is at it
-        if (!pool_open(L, slots, ctl, work, n_samp, lane, POOL_NONE, cam, exact, drained)) return false;
+        if (!pool_open<LISTS>(L, slots, ctl, work, n_samp, lane, POOL_NONE, cam, exact, drained)) return false;
     }
     if (got && ahead_at >= first && ahead_at < first + 64u) {
         bool unused = false;
-        (void)pool_open(L, slots, ctl, work, n_samp, lane, slot, cam, exact, unused);
+        (void)pool_open<LISTS>(L, slots, ctl, work, n_samp, lane, slot, cam, exact, unused);
     }
     return got;
 }
@@ -1470,7 +1475,7 @@ RT_DEV void pool_finish(const RtLaunch& L, uint32_t* slots, unsigned long long* 
     if (uniform_u32(old) == n) pool_write(L, slots, accum, sl, lane, rgba, linear, fold);
 }
 
-template <bool FOLD>
+template <bool FOLD, bool LISTS>
 RT_DEV void render_pool_body(const Scene& sc, uint32_t* __restrict__ rgba, float4* __restrict__ linear,
                              unsigned long long* __restrict__ segments, uint32_t* __restrict__ work,
                              float4* __restrict__ fold_all, const float4* __restrict__ camterms, const RtCamera& cam,
@@ -1555,7 +1560,7 @@ RT_DEV void render_pool_body(const Scene& sc, uint32_t* __restrict__ rgba, float
         if (want != 0ull && !drained) {
             uint32_t sl = 0u, first = 0u;
             uint4 head = make_uint4(0u, 0u, 0u, 0u);
-            if (pool_next_batch(L, slots, ctl, work, n_samp, ahead_at, lane, cam, sc.exact, hint, sl, first, head, drained)) {
+            if (pool_next_batch<LISTS>(L, slots, ctl, work, n_samp, ahead_at, lane, cam, sc.exact, hint, sl, first, head, drained)) {
                 Slot u;
                 u.open = true; u.left = 0u;
                 u.x0 = uniform_u32(head.x);
@@ -1563,9 +1568,9 @@ RT_DEV void render_pool_body(const Scene& sc, uint32_t* __restrict__ rgba, float
                 u.ly0 = uniform_u32(head.z);
                 uint32_t completed = 0u;
                 // (the list's length sits in the slot like x0: once the batch is this wavefront's the slot cannot change hands)
-                const uint32_t ul_k = uniform_u32(slots[sl * 8u + 6u]);
-                primary_batch(sc, tile, geo0, cam, L, seed, T, u, sl, first, n_samp, accum, fold, q, cand, pool_list(L, sl), ul_k,
-                              q_count, completed, nseg, st);
+                const uint32_t ul_k = LISTS ? uniform_u32(slots[sl * 8u + 6u]) : RT_UL_NONE;
+                primary_batch<LISTS>(sc, tile, geo0, cam, L, seed, T, u, sl, first, n_samp, accum, fold, q, cand, pool_list(L, sl), ul_k,
+                                     q_count, completed, nseg, st);
                 q_head = 0u;
                 if (completed) pool_finish(L, slots, accum, sl, completed, lane, rgba, linear, fold);
                 continue;
@@ -1726,8 +1731,8 @@ RT_DEV void render_queue_stream_body(const Scene& sc, uint32_t* __restrict__ rgb
             }
             if (ul_k == RT_UL_NONE) { primary = true; break; }
             uint32_t completed = 0u;
-            primary_batch(sc, whole, geo0, cam, L, seed, T, cur ? u1 : u0, cur, next_samp, n_samp, accum, fold, q, cand, ul, ul_k,
-                          q_count, completed, nseg, st);
+            primary_batch<true>(sc, whole, geo0, cam, L, seed, T, cur ? u1 : u0, cur, next_samp, n_samp, accum, fold, q, cand, ul, ul_k,
+                                q_count, completed, nseg, st);
             q_head = 0u;
             next_samp = next_samp + 64u < n_samp ? next_samp + 64u : n_samp;
             if (cur) u1.left -= completed; else u0.left -= completed;
@@ -1875,7 +1880,18 @@ rt_render_pool(const float4* geom, const float4* exact, const float4* shade, con
                float4* linear, unsigned long long* segments, uint32_t* work, float4* fold, const float4* camterms,
                RtCamera cam, RtLaunch L) {
     Scene sc = {geom, exact, shade, mat};
-    render_pool_body<false>(sc, rgba, linear, segments, work, nullptr, camterms, cam, L);
+    render_pool_body<false, true>(sc, rgba, linear, segments, work, nullptr, camterms, cam, L);
+}
+
+// rt_render_pool built without the pixel units' sphere lists, for the launches that have none (scenes of a handful of
+// spheres, or no room in LDS): the list set-up's double-precision arithmetic costs the pooled kernel registers it is
+// short of (two-sphere 1080p frame at 100 spp: 4.4 against 4.75 ms).
+extern "C" __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6)))
+rt_render_pool_plain(const float4* geom, const float4* exact, const float4* shade, const uint32_t* mat, uint32_t* rgba,
+                     float4* linear, unsigned long long* segments, uint32_t* work, float4* fold, const float4* camterms,
+                     RtCamera cam, RtLaunch L) {
+    Scene sc = {geom, exact, shade, mat};
+    render_pool_body<false, false>(sc, rgba, linear, segments, work, nullptr, camterms, cam, L);
 }
 
 // The same two kernels in fold-order mode (RtParams.sample_chunk = 0): finished samples are parked in the
@@ -1895,7 +1911,7 @@ rt_render_pool_fold(const float4* geom, const float4* exact, const float4* shade
                     float4* linear, unsigned long long* segments, uint32_t* work, float4* fold, const float4* camterms,
                     RtCamera cam, RtLaunch L) {
     Scene sc = {geom, exact, shade, mat};
-    render_pool_body<true>(sc, rgba, linear, segments, work, fold, camterms, cam, L);
+    render_pool_body<true, true>(sc, rgba, linear, segments, work, fold, camterms, cam, L);
 }
 
 extern "C" __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(5)))

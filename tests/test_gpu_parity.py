@@ -18,6 +18,15 @@ def rt():
     return ray_tracing_amd
 
 
+# The pooled kernel has a build without the pixel units' sphere lists, run where a launch has none (fewer than 16
+# spheres, or no room in LDS beside 64-pixel units): which of the two runs is not what most tests here are about.
+POOLED = ("rt_render_pool", "rt_render_pool_plain")
+
+
+def same_kernel(name, expected):
+    return name in POOLED if expected == "rt_render_pool" else name == expected
+
+
 @pytest.fixture(scope="module")
 def hip(rt):
     w = rt.HipWorld(0)
@@ -171,7 +180,7 @@ def test_c2_full_size(oracle, rt, hip):
     p = rt.cpu_params(100, 50, seed=1, sample_chunk=1)
     hip.upload_scene(sp)
     full = hip.render(cam, p, linear=True)
-    assert hip.last_kernel_name() == "rt_render_pool"
+    assert hip.last_kernel_name() == "rt_render_pool_plain"                          # (two spheres: no unit lists)
     assert full["linear"].shape == (1080, 1920, 4) and np.isfinite(full["linear"]).all()
     assert (full["rgba"][..., 3] == 255).all() and full["rays"] > 1920 * 1080 * 100
     ocam = oracle.camera_f32_from_rt(cam.block)
@@ -331,7 +340,7 @@ def test_camera_ray_batches_edge_cases(oracle, rt, hip):
     p = rt.DeviceGUI(samples_per_pixel=24, max_depth=30, seed=8, sample_chunk=1)
     got, _ = check_render(oracle, hip, cam, sp, p)
     check_render(oracle, hip, cam, sp, p, row0=41, rows=1)
-    assert hip.last_kernel_name() == "rt_render_pool"
+    assert hip.last_kernel_name() in POOLED
     for unit, no_queue, scheduler, kernel in ((None, True, "auto", "rt_render"), (None, False, "auto", "rt_render_pool"),
                                               ((8, 8), False, "wave", "rt_render_queue"), ((16, 1), False, "wave", "rt_render_queue"),
                                               ((1, 1), False, "wave", "rt_render_queue"), ((8, 8), False, "pool", "rt_render_pool"),
@@ -339,7 +348,7 @@ def test_camera_ray_batches_edge_cases(oracle, rt, hip):
                                               ((2, 2), False, "pool", "rt_render_pool")):
         hip.debug_schedule(unit=unit, no_queue=no_queue, scheduler=scheduler)
         other = hip.render(cam, p, linear=True)
-        assert hip.last_kernel_name() == kernel
+        assert same_kernel(hip.last_kernel_name(), kernel)
         hip.debug_schedule()
         assert np.array_equal(other["linear"], got["linear"]) and other["rays"] == got["rays"], (unit, scheduler)
     # depth 0 traces nothing: no pool to run
@@ -385,7 +394,7 @@ def test_camera_ray_scan_with_hostile_cameras(oracle, rt, hip):
     for name, sp, lookfrom, lookat, vfov in cases:
         cam = rt.Camera.look_at(16.0 / 9.0, 96, vfov, lookfrom, lookat)
         got, _ = check_render(oracle, hip, cam, sp, p)
-        assert hip.last_kernel_name() == ("rt_render_queue_stream" if len(sp) > 1024 else "rt_render_pool"), name
+        assert hip.last_kernel_name() == "rt_render_queue_stream" if len(sp) > 1024 else hip.last_kernel_name() in POOLED, name
         hits = hip.primary_hits(cam, p)
         ref = oracle.primary_hits(oracle.camera_f32_from_rt(cam.block), sp, p.t_min, p.t_max, p.flags)
         assert np.array_equal(hits, ref), name
@@ -412,7 +421,7 @@ def test_scenes_without_a_usable_bound_stay_off_the_batch_kernels(oracle, rt, hi
     # scene radius R ~ 120 (the r = 100 ground sphere and the mirrors at z = -50, -110)
     near = rt.Camera.look_at(16.0 / 9.0, 96, 2.0, (0.0, 3.0e4, 1.0e5), (0.0, 0.0, -40.0))     # ~1000 R away
     check_render(oracle, hip, near, base, p)
-    assert hip.last_kernel_name() == "rt_render_pool"
+    assert hip.last_kernel_name() in POOLED
     away = rt.Camera.look_at(16.0 / 9.0, 96, 0.02, (0.0, 3.0e5, 1.0e6), (0.0, 0.0, -40.0))    # ~9000 R away
     check_render(oracle, hip, away, base, p, as_scheduled=True)
     assert hip.last_kernel_name() == "rt_render"
@@ -421,7 +430,7 @@ def test_scenes_without_a_usable_bound_stay_off_the_batch_kernels(oracle, rt, hi
     assert hip.last_kernel_name() == "rt_render"
     hip.upload_scene(base)
     hip.render(cam, p)
-    assert hip.last_kernel_name() == "rt_render_pool"
+    assert hip.last_kernel_name() in POOLED
 
 
 def test_randomised_scenes_all_modes(oracle, rt, hip):
@@ -473,7 +482,7 @@ def test_fold_order_runs_on_the_batch_kernels_and_on_the_pixel_kernel(oracle, rt
         for unit in ((8, 8), (1, 1), (16, 1), (2, 2)):
             hip.debug_schedule(unit=unit, scheduler=scheduler)
             other = hip.render(cam, p, linear=True)
-            assert hip.last_kernel_name() == kernel
+            assert same_kernel(hip.last_kernel_name(), kernel)
             hip.debug_schedule()
             assert np.array_equal(other["linear"].view(np.uint32), got["linear"].view(np.uint32)) and other["rays"] == got["rays"]
     hip.debug_schedule(no_queue=True)
@@ -658,10 +667,10 @@ def test_scheduler_is_chosen_by_launch_size_and_does_not_change_the_image(rt, hi
     p = rt.DeviceGUI(samples_per_pixel=2, max_depth=12, seed=6, sample_chunk=1)
     hip.upload_scene(sp)
     small = hip.render(cam, p, linear=True)
-    assert hip.last_kernel_name() == "rt_render_pool"
+    assert hip.last_kernel_name() in POOLED
     hip.debug_schedule(unit=(1, 1))
     hip.render(cam, p)
-    assert hip.last_kernel_name() == "rt_render_pool"
+    assert hip.last_kernel_name() in POOLED
     hip.debug_schedule(unit=(1, 1), scheduler="wave")
     large = hip.render(cam, p, linear=True)
     assert hip.last_kernel_name() == "rt_render_queue"
@@ -672,7 +681,7 @@ def test_scheduler_is_chosen_by_launch_size_and_does_not_change_the_image(rt, hi
             p.block_dim = block
             hip.debug_schedule(unit=unit, scheduler="pool")
             other = hip.render(cam, p, linear=True)
-            assert hip.last_kernel_name() == "rt_render_pool"
+            assert hip.last_kernel_name() in POOLED
             hip.debug_schedule()
             assert np.array_equal(other["linear"], small["linear"]) and other["rays"] == small["rays"], (block, unit)
 
@@ -751,7 +760,7 @@ def _interleaved_tiles_equal_the_frame(torch, hip, cam, p, full, kernel):
             d_rgba = torch.zeros((len(mine) * TR, W, 4), dtype=torch.uint8, device="cuda")
             d_lin = torch.zeros((len(mine) * TR, W, 4), dtype=torch.float32, device="cuda")
             r, _ = hip.render_tiles_device(cam, p, TR, rank, world, len(mine), d_rgba.data_ptr(), d_lin.data_ptr())
-            assert hip.last_kernel_name() == kernel
+            assert same_kernel(hip.last_kernel_name(), kernel)
             rays += r
             h_rgba, h_lin = d_rgba.cpu().numpy(), d_lin.cpu().numpy()
             for k, t in enumerate(mine):
