@@ -39,7 +39,7 @@ struct rt_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipModule_t module = nullptr;
-    hipFunction_t f_render = nullptr, f_render_queue = nullptr, f_render_queue_fold = nullptr, f_render_queue_stream_fold = nullptr, f_render_stream = nullptr, f_render_queue_stream = nullptr, f_hits = nullptr, f_random = nullptr, f_assemble = nullptr, f_camera_terms = nullptr, f_render_pool = nullptr, f_render_pool_fold = nullptr, f_render_pool_plain = nullptr;
+    hipFunction_t f_render = nullptr, f_render_queue = nullptr, f_render_queue_fold = nullptr, f_render_queue_stream_fold = nullptr, f_render_stream = nullptr, f_render_queue_stream = nullptr, f_hits = nullptr, f_random = nullptr, f_assemble = nullptr, f_camera_terms = nullptr, f_render_pool = nullptr, f_render_pool_fold = nullptr, f_render_pool_plain = nullptr, f_render_queue_boxes = nullptr, f_render_pool_boxes = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     void *d_geom = nullptr, *d_exact = nullptr, *d_shade = nullptr, *d_mat = nullptr;
     void* d_camterms = nullptr;         // per sphere {A, B, C, sq} of the camera-ray scan, rewritten by every launch (rt_camera_terms)
@@ -50,6 +50,7 @@ struct rt_ctx {
     float scan_scale = 1.0f;
     double scene_radius = 0.0;
     uint32_t n_spheres = 0, n_padded = 0;
+    uint32_t n_blocks = 0;            // blocks of 32 device spheres with a bounding box behind the filter data; 0: the list is not sorted
     bool have_scene = false;
     void *d_rgba = nullptr, *d_linear = nullptr, *d_hits = nullptr, *d_counter = nullptr;
     size_t counter_need = RT_COUNTER_BYTES, cap_counter = 0;   // counter block the loaded code object asks for; bytes d_counter holds
@@ -163,6 +164,8 @@ int load_image(rt_ctx* c, const void* image) {
     if (hipModuleGetFunction(&c->f_render_pool, m, "rt_render_pool") != hipSuccess) { c->f_render_pool = nullptr; (void)hipGetLastError(); }
     if (hipModuleGetFunction(&c->f_render_pool_fold, m, "rt_render_pool_fold") != hipSuccess) { c->f_render_pool_fold = nullptr; (void)hipGetLastError(); }
     if (hipModuleGetFunction(&c->f_render_pool_plain, m, "rt_render_pool_plain") != hipSuccess) { c->f_render_pool_plain = nullptr; (void)hipGetLastError(); }
+    if (hipModuleGetFunction(&c->f_render_queue_boxes, m, "rt_render_queue_boxes") != hipSuccess) { c->f_render_queue_boxes = nullptr; (void)hipGetLastError(); }
+    if (hipModuleGetFunction(&c->f_render_pool_boxes, m, "rt_render_pool_boxes") != hipSuccess) { c->f_render_pool_boxes = nullptr; (void)hipGetLastError(); }
     c->f_render_queue_fold = fqf; c->f_render_queue_stream_fold = fqsf; c->f_render = fr; c->f_render_queue = fq; c->f_render_queue_stream = fqs; c->f_render_stream = fs; c->f_hits = fh; c->f_random = fx; c->f_assemble = fa; c->f_camera_terms = fct;
     return 0;
 }
@@ -274,18 +277,17 @@ RtLaunch make_launch(const rt_ctx* c, const RtCamera* cam, const RtParams* p, ui
         };
         // Short launches run with the units pooled per workgroup (rt_render_pool, see launch_render): the end of the launch,
         // when the wavefronts run out of units one by one, then costs little -- whole workgroups finish the last units --
-        // and the units can have their full size.  In steady state the pooled kernel is behind, 1 % on the book scene and
-        // 9 % in the mirror hall (its bookkeeping per camera-ray batch weighs more since the units' sphere lists shortened
-        // the batches, and it holds more wave-uniform state than there are scalar registers).  The crossover is a launch
-        // length, about 120 ms of kernel time, estimated here as samples per resident wavefront (24 per compute unit)
-        // x (spheres + 56) < 60 M, a segment's cost being 9 operations per sphere and some 500 beside the scan.
+        // and the units can have their full size.  In steady state the pooled kernel is 7-8 % behind (its bookkeeping per
+        // camera-ray batch weighs more since the units' sphere lists shortened the batches, and it holds more
+        // wave-uniform state than there are scalar registers).  The crossover is a launch length, roughly 70-100 ms of
+        // kernel time, estimated here as samples per resident wavefront (24 per compute unit) x (spheres + 56) < 44 M.
         // Measured with 16x1 units (kernel ms, per-wavefront / pooled; one box): book scene 4K at 500 spp, depth 50 (486
-        // spheres): whole frame = 675 k samples per wavefront 760 / 766, half 380 / 384, a quarter (169 k x 542 = 91 M)
-        // 190 / 194, an eighth (46 M) 97.9 / 96.9, a sixteenth 53.0 / 50.3; mirror hall 8K at 256 spp, depth 100 (66
-        // spheres): whole frame = 1.38 M samples per wavefront 344 / 376, half (691 k x 122 = 84 M) 177 / 189, a quarter
-        // (42 M) 97.2 / 95.0, an eighth 48.5 / 48.0, a sixteenth 24.6 / 24.3.
+        // spheres, bounce scan with block boxes): half the frame 256 / 277, a quarter (169 k samples per wavefront x 542 =
+        // 91 M) 129 / 139, an eighth (46 M) 67.8 / 69.9, a sixteenth (23 M) 41.0 / 37.3; mirror hall 8K at 256 spp, depth
+        // 100 (66 spheres): whole frame 349 / 373, half (691 k x 122 = 84 M) 180 / 187, a quarter (42 M) 96.8 / 94.1, an
+        // eighth 49.3 / 47.7, a sixteenth 24.9 / 24.2.
         const uint64_t launch_samples = (uint64_t)cam->image_width * rows_local * spp;
-        const bool small_launch = launch_samples * (c->n_padded + 56u) < resident * 60000000ull;
+        const bool small_launch = launch_samples * (c->n_padded + 56u) < resident * 44000000ull;
         const bool pool_able = L.chunk == 1u && L.n_chunks > 1u && queue_kernel_fits(c, cam, spp) && p->max_depth > 0u &&
                                c->n_padded <= RT_TILE_SPHERES && (fold ? c->f_render_pool_fold : c->f_render_pool) != nullptr &&
                                c->dbg_scheduler != RT_SCHED_WAVE;
@@ -315,6 +317,8 @@ RtLaunch make_launch(const rt_ctx* c, const RtCamera* cam, const RtParams* p, ui
     }
     for (int k = 0; k < 3; k++) L.translate[k] = c->translate[k];
     L.scan_scale = c->scan_scale;
+    L.scan_blocks = c->n_blocks;
+    if (std::getenv("RT_EXP_NO_BOXES")) L.scan_blocks = 0u;                      // timing experiments only
     L.units_bottom_up = 0u;
     if (const char* e = std::getenv("RT_EXP_UNITS_BOTTOM_UP")) L.units_bottom_up = std::atoi(e) ? 1u : 0u;   // timing experiments only
     for (L.unit_shift = 0; (1u << L.unit_shift) < L.unit_w; L.unit_shift++) {}
@@ -390,6 +394,12 @@ int launch_render(rt_ctx* c, const RtCamera* cam, const RtParams* p, RtLaunch L,
         } else {
             f = one_tile ? c->f_render_queue : c->f_render_queue_stream;
             c->last_kernel = one_tile ? "rt_render_queue" : "rt_render_queue_stream";
+            if (one_tile && L.scan_blocks != 0u && c->f_render_queue_boxes) {   // the build with the blocks' boxes in the bounce scan
+                f = c->f_render_queue_boxes;
+                c->last_kernel = "rt_render_queue_boxes";
+            } else if (one_tile && L.pool_slots == 0u) {
+                L.scan_blocks = 0u;
+            }
         }
         if (one_tile && p->block_dim == 0u) {
             // the one-tile kernels are built for six waves per SIMD; with 512-thread workgroups three of them (24
@@ -400,14 +410,28 @@ int launch_render(rt_ctx* c, const RtCamera* cam, const RtParams* p, RtLaunch L,
         }
         // the unit lists are the first thing to go where a workgroup's LDS (64 KiB) is short: 16 entries, 8, none
         auto queue_lds = [&](unsigned cap) {
-            return (one_tile ? c->n_padded : RT_Q_STREAM_TILE) * 32u + waves * (RT_Q_CAND_CAP * 128u + 48u * P + RT_Q_WORDS * 256u + RT_UL_BYTES(cap));
+            return (one_tile ? c->n_padded * 32u + L.scan_blocks * 32u : RT_Q_STREAM_TILE * 32u + (L.scan_blocks ? RT_Q_STREAM_TILE : 0u)) +
+                   waves * (RT_Q_CAND_CAP * 128u + 48u * P + RT_Q_WORDS * 256u + RT_UL_BYTES(cap));
         };
         auto pool_lds = [&](unsigned cap) {
-            return c->n_padded * 32u + 2u * waves * 32u + 16u + 2u * waves * 24u * P + 2u * waves * RT_UL_BYTES(cap) + waves * (RT_Q_CAND_CAP * 128u + RT_Q_WORDS * 256u);
+            return c->n_padded * 32u + L.scan_blocks * 32u + 2u * waves * 32u + 16u + 2u * waves * 24u * P + 2u * waves * RT_UL_BYTES(cap) + waves * (RT_Q_CAND_CAP * 128u + RT_Q_WORDS * 256u);
         };
+        // Which build.  The per-wavefront kernel and the pooled one each come with and without the blocks' boxes in the
+        // bounce scan (fold order: with), the pooled one also without the units' lists: code a launch does not use still
+        // costs it registers.
+        hipFunction_t pool_f = nullptr;
+        const char* pool_name = nullptr;
+        if (L.pool_slots != 0u) {
+            // the boxes and the lists are the first things to go where a workgroup's LDS (64 KiB) is short
+            while (L.ulist_cap != 0u && pool_lds(L.ulist_cap) > 65536u) L.ulist_cap = L.ulist_cap > 8u ? 8u : 0u;
+            if (pool_lds(0u) > 65536u) L.scan_blocks = 0u;
+            if (L.fold) { pool_f = c->f_render_pool_fold; pool_name = "rt_render_pool_fold"; }
+            else if (L.scan_blocks != 0u && c->f_render_pool_boxes) { pool_f = c->f_render_pool_boxes; pool_name = "rt_render_pool_boxes"; }
+            else { pool_f = c->f_render_pool; pool_name = "rt_render_pool"; L.scan_blocks = 0u; }
+        }
         if (L.ulist_cap != 0u) {
-            // (and they must not cost a workgroup per compute unit: a wave of occupancy is worth more than long lists)
-            hipFunction_t fq = L.pool_slots ? (L.fold ? c->f_render_pool_fold : c->f_render_pool) : f;
+            // (and the lists must not cost a workgroup per compute unit: a wave of occupancy is worth more)
+            hipFunction_t fq = L.pool_slots ? pool_f : f;
             auto resident_with = [&](unsigned cap) {
                 const unsigned bytes = L.pool_slots ? pool_lds(cap) : queue_lds(cap);
                 int n = 0;
@@ -424,9 +448,9 @@ int launch_render(rt_ctx* c, const RtCamera* cam, const RtParams* p, RtLaunch L,
         // waits for its own units' last paths and the launch's last units are finished by whole workgroups: it wins on
         // small launches (an eighth of the book frame 3 %, a sixteenth 18 %).  Decided with the unit shape in make_launch.
         if (L.pool_slots != 0u) {
-            f = L.fold ? c->f_render_pool_fold : c->f_render_pool;
-            c->last_kernel = L.fold ? "rt_render_pool_fold" : "rt_render_pool";
-            if (!L.fold && L.ulist_cap == 0u && c->f_render_pool_plain) {   // the build without the units' sphere lists
+            f = pool_f;
+            c->last_kernel = pool_name;
+            if (!L.fold && L.ulist_cap == 0u && L.scan_blocks == 0u && c->f_render_pool_plain) {   // neither lists nor boxes
                 f = c->f_render_pool_plain;
                 c->last_kernel = "rt_render_pool_plain";
             }
@@ -487,7 +511,7 @@ int launch_hits(rt_ctx* c, const RtCamera* cam, const RtParams* p, RtLaunch L, v
     unsigned grid, block;
     launch_geometry(p, L.n_wave_tiles, &grid, &block);
     RtCamera cam_copy = *cam;
-    void* args[] = {&c->d_geom, &c->d_exact, &d_hits, &cam_copy, &L};
+    void* args[] = {&c->d_geom, &c->d_exact, &c->d_mat, &d_hits, &cam_copy, &L};
     if (grid > 0)
         RT_HIP(c, hipModuleLaunchKernel(c->f_hits, grid, 1, 1, block, 1, 1, (unsigned)lds_bytes(c, block, 64u), c->stream, args, nullptr));
     RT_HIP(c, hipStreamSynchronize(c->stream));
@@ -687,16 +711,71 @@ int rt_upload_scene(rt_ctx* c, const RtSphere* spheres, uint32_t n) {
         scene_radius = R;
     }
     const double s2 = (double)sigma * (double)sigma;
-    std::vector<float> geom((size_t)n_padded * 4), exact((size_t)n_padded * 4), shade((size_t)n_padded * 12, 0.0f);
-    std::vector<uint32_t> mat(n_padded);
+    // Device order: spheres sorted along a space-filling curve, so that 32 consecutive ones -- one block of the scans --
+    // lie close together and the block's bounding box is small (scan_tile skips a block no lane's ray can reach).
+    // The few spheres that are large against the scene (a ground sphere) come first: their blocks' boxes are large
+    // whatever their neighbours.  order[i] = the caller's index of device sphere i.
+    std::vector<uint32_t> order(n);
+    for (uint32_t i = 0; i < n; i++) order[i] = i;
+    const bool sorted = n >= 128u && scene_radius > 0.0 && !std::getenv("RT_EXP_NO_SORT");   // (fewer: a scan costs less than the boxes' tests and registers)
+    if (sorted) {
+        float lo[3], hi[3];
+        std::vector<float> v(n);
+        double extent = 0.0;
+        for (int k = 0; k < 3; k++) {
+            for (uint32_t i = 0; i < n; i++) v[i] = spheres[i].center[k];
+            std::nth_element(v.begin(), v.begin() + n / 50, v.end());
+            lo[k] = v[n / 50];
+            std::nth_element(v.begin(), v.begin() + (n - 1 - n / 50), v.end());
+            hi[k] = v[n - 1 - n / 50];
+            extent = std::max(extent, (double)hi[k] - (double)lo[k]);
+        }
+        if (!(extent > 0.0) || !std::isfinite(extent)) extent = 1.0;
+        auto spread = [](uint32_t x) {                               // 10 bits -> every third bit
+            x &= 0x3ffu;
+            x = (x | (x << 16)) & 0x030000ffu;
+            x = (x | (x << 8)) & 0x0300f00fu;
+            x = (x | (x << 4)) & 0x030c30c3u;
+            x = (x | (x << 2)) & 0x09249249u;
+            return x;
+        };
+        std::vector<uint64_t> key(n);
+        for (uint32_t i = 0; i < n; i++) {
+            uint32_t q[3];
+            for (int k = 0; k < 3; k++) {
+                double t = ((double)spheres[i].center[k] - (double)lo[k]) / extent * 1024.0;
+                if (!(t > 0.0)) t = 0.0;
+                if (t > 1023.0) t = 1023.0;
+                q[k] = (uint32_t)t;
+            }
+            const bool big = std::fabs((double)spheres[i].radius) > extent / 8.0;
+            const uint64_t morton = big ? 0u : (1ull << 30) | spread(q[0]) | (spread(q[1]) << 1) | (spread(q[2]) << 2);
+            key[i] = (morton << 32) | i;
+        }
+        std::sort(key.begin(), key.end());
+        for (uint32_t i = 0; i < n; i++) order[i] = (uint32_t)(key[i] & 0xffffffffu);
+    }
+    // after the spheres' filter data: per block of 32 spheres two float4, the corners of a box (coordinates relative to
+    // T) that holds every point at which the exact test can report a hit of a sphere of the block, for rays leaving
+    // from T: each sphere's own |r| (1 + 2^-10) + 2^-9 |c - T| + 2^-20 R beyond its centre (the kernel adds 2^-9 |o - T|
+    // for its ray; the exact test's tolerance is below 2^-11 |c - o|)
+    const uint32_t n_blocks = (n_padded + 31u) / 32u;
+    std::vector<float> geom(((size_t)n_padded + 2u * n_blocks) * 4), exact((size_t)n_padded * 4), shade((size_t)n_padded * 12, 0.0f);
+    std::vector<uint32_t> mat((size_t)n_padded * 2u);
+    for (uint32_t b = 0; b < n_blocks; b++) {
+        float* lo4 = &geom[4 * ((size_t)n_padded + 2u * b)];
+        lo4[0] = lo4[1] = lo4[2] = INFINITY; lo4[3] = 0.0f;
+        lo4[4] = lo4[5] = lo4[6] = -INFINITY; lo4[7] = 0.0f;
+    }
     for (uint32_t i = 0; i < n_padded; i++) {
         float* g = &geom[4 * (size_t)i];
         float* x = &exact[4 * (size_t)i];
         float* s = &shade[8 * (size_t)i];
+        mat[(size_t)n_padded + i] = i < n ? order[i] : i;
         if (i < n) {
-            const RtSphere& sp = spheres[i];
+            const RtSphere& sp = spheres[order[i]];
             if (sp.material < RT_MAT_DIFFUSE || sp.material > RT_MAT_DIELECTRIC)
-                return fail(c, RT_ERR_INVALID, "unknown material tag in sphere " + std::to_string(i));
+                return fail(c, RT_ERR_INVALID, "unknown material tag in sphere " + std::to_string(order[i]));
             const float rr = sp.radius * sp.radius;   // radius*radius, library.cu:203 / lib.rs:101
             double cc = 0.0;
             for (int k = 0; k < 3; k++) {
@@ -706,6 +785,15 @@ int rt_upload_scene(rt_ctx* c, const RtSphere* spheres, uint32_t n) {
             }
             const double m = (double)rr * (1.0 + 0x1p-17) - cc * (1.0 - 0x1p-18);
             g[3] = std::nextafter((float)m, INFINITY) * (float)s2;   // times sigma^2, a power of two: exact
+            {
+                float* lo4 = &geom[4 * ((size_t)n_padded + 2u * (i / 32u))];
+                const double ext = std::fabs((double)sp.radius) * (1.0 + 0x1p-10) + 0x1p-9 * std::sqrt(cc) + 0x1p-20 * (scene_radius > 0.0 ? scene_radius : 0.0);
+                for (int k = 0; k < 3; k++) {
+                    const float a = std::nextafter((float)((double)g[k] - ext), -INFINITY), b = std::nextafter((float)((double)g[k] + ext), INFINITY);
+                    if (!(a >= lo4[k])) lo4[k] = a;                   // (a NaN sticks: the box then never excludes anything)
+                    if (!(b <= lo4[4 + k])) lo4[4 + k] = b;
+                }
+            }
             x[3] = rr;
             float param = sp.param;
             if (sp.material == RT_MAT_REFLECT) param = param < 1.0f ? param : 1.0f;   // library.cu:144
@@ -733,23 +821,25 @@ int rt_upload_scene(rt_ctx* c, const RtSphere* spheres, uint32_t n) {
         }
     }
     size_t bytes = (size_t)n_padded * 16u;
+    const size_t geom_bytes = bytes + (size_t)n_blocks * 32u;
     void** owned[] = {&c->d_geom, &c->d_exact, &c->d_shade, &c->d_mat, &c->d_camterms};
     for (void** p : owned) if (*p) { RT_HIP(c, hipFree(*p)); *p = nullptr; }
     c->have_scene = false;
-    RT_HIP(c, hipMalloc(&c->d_geom, bytes));
+    RT_HIP(c, hipMalloc(&c->d_geom, geom_bytes));
     RT_HIP(c, hipMalloc(&c->d_exact, bytes));
     RT_HIP(c, hipMalloc(&c->d_shade, 3 * bytes));
-    RT_HIP(c, hipMalloc(&c->d_mat, (size_t)n_padded * 4u));
+    RT_HIP(c, hipMalloc(&c->d_mat, (size_t)n_padded * 8u));                       // material tags, then the caller's index of each device sphere
     RT_HIP(c, hipMalloc(&c->d_camterms, bytes));
-    RT_HIP(c, hipMemcpy(c->d_geom, geom.data(), bytes, hipMemcpyHostToDevice));
+    RT_HIP(c, hipMemcpy(c->d_geom, geom.data(), geom_bytes, hipMemcpyHostToDevice));
     RT_HIP(c, hipMemcpy(c->d_exact, exact.data(), bytes, hipMemcpyHostToDevice));
     RT_HIP(c, hipMemcpy(c->d_shade, shade.data(), 3 * bytes, hipMemcpyHostToDevice));
-    RT_HIP(c, hipMemcpy(c->d_mat, mat.data(), (size_t)n_padded * 4u, hipMemcpyHostToDevice));
+    RT_HIP(c, hipMemcpy(c->d_mat, mat.data(), (size_t)n_padded * 8u, hipMemcpyHostToDevice));
     for (int k = 0; k < 3; k++) c->translate[k] = T[k];
     c->scan_scale = sigma;
     c->scene_radius = scene_radius;
     c->n_spheres = n;
     c->n_padded = n_padded;
+    c->n_blocks = sorted ? n_blocks : 0u;
     c->have_scene = true;
     return 0;
 }

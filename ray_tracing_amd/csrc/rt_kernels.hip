@@ -129,12 +129,20 @@ RT_DEV V3 random_unit_vector(Rng& g, Stats& st) {
 
 // ---------------------------------------------------------------- closest hit
 struct Best { float t; int idx; };
+#ifdef RT_BOXCHECK   // diagnostics build: see scan_tile
+__device__ unsigned long long* rt_dbg_ptr = nullptr;
+#define RT_DBG_SET(p) rt_dbg_ptr = (p)
+#else
+#define RT_DBG_SET(p)
+#endif
 
 // Exact acceptance of Sphere::hit (library.cu:205-218, lib.rs:103-117) for one sphere against the
-// current upper bound.  Ties keep the lower index because the bound is strict.  The first line skips
+// current upper bound.  Ties keep the lower index -- the CALLER's index: the device list is sorted in space, orig[] maps
+// back, and two spheres reporting the very same root (a small sphere resting on the ground, hit at the contact) are
+// told apart as the reference's loop over its list does, first one wins (library.cu:243-251).  The first line skips
 // the square root and the divides where no root can qualify: with t_min >= 0, a root beyond t_min needs
 // h > 0 or the origin inside the sphere (ncc > 0); otherwise sqrt(disc) <= |h| and both roots are <= 0.
-RT_DEV void accept_exact(float h, float ncc, float disc, float a, float t_min, int idx, Best& b) {
+RT_DEV void accept_exact(float h, float ncc, float disc, float a, float t_min, int idx, const uint32_t* __restrict__ orig, Best& b) {
     if (disc >= 0.0f && (h > 0.0f || ncc > 0.0f)) {
 #ifdef RT_ABL_EXACT   // ablation (changes the image): what the exact test's IEEE square root and divides cost
         float s = __builtin_amdgcn_sqrtf(disc);
@@ -158,6 +166,7 @@ RT_DEV void accept_exact(float h, float ncc, float disc, float a, float t_min, i
             root = root_b;
             ok = (t_min < root_b) && (root_b < b.t);
         }
+        if (root == b.t && b.idx >= 0 && t_min < root) ok = orig[idx] < orig[b.idx];   // a tie: the earlier sphere of the caller's list
         if (ok) { b.t = root; b.idx = idx; }
     }
 }
@@ -174,7 +183,9 @@ RT_DEV void sphere_terms(float cx, float cy, float cz, float rr, V3 o, V3 d, flo
 // LDS sphere tile of one workgroup:
 //   geo[i] = {cx - Tx, cy - Ty, cz - Tz, m}   scan filter only (T, m: see scan_tile)
 //   exa[i] = {cx, cy, cz, r*r}                exact test (LDS, or global memory in the queue kernels)
-struct Tile { const float4* geo; const float4* exa; };
+// box: two float4 per block of 32 spheres (scan_tile), or NULL; orig: the caller's index of every device sphere (the
+// whole list's, whatever the tile)
+struct Tile { const float4* geo; const float4* exa; const float4* box; const uint32_t* orig; };
 
 // Per-lane list of candidate spheres of the tile being scanned, kept in LDS as a column of a
 // [cap][64] u16 array per wavefront (lane l owns column l, so pushes never conflict).
@@ -198,7 +209,7 @@ RT_DEV void drain(const Tile& tile, int base, Cand& c, V3 o, V3 d, float a, floa
         float4 g = tile.exa[i];
         float h, ncc, disc;
         sphere_terms(g.x, g.y, g.z, g.w, o, d, a, h, ncc, disc);
-        accept_exact(h, ncc, disc, a, t_min, base + (int)i, b);
+        accept_exact(h, ncc, disc, a, t_min, base + (int)i, tile.orig, b);
     }
     c.n = 0u;
 }
@@ -314,7 +325,7 @@ RT_DEV void filter_step(const RayTerms& r, const float4* p, uint32_t& miss) {
     }
 }
 
-template <bool HALF>
+template <bool HALF, bool BOXES = false>
 RT_DEV void scan_tile(const Tile& tile, uint32_t count, int base, V3 T, float sigma,
                       V3 o, V3 d, float a, float t_min, Best& b, Cand& c, Stats& st) {
     st.wave(1);
@@ -326,8 +337,47 @@ RT_DEV void scan_tile(const Tile& tile, uint32_t count, int base, V3 T, float si
     r.e = -vdot(r.uf, op);
     r.w = v3((2.0f * s2) * op.x, (2.0f * s2) * op.y, (2.0f * s2) * op.z);
     r.k0 = -(vdot(op, op) * (1.0f - 0x1p-18f)) * s2;
+    // Block boxes (tile.box != NULL): the list is sorted in space and every block of 32 spheres has a box outside
+    // which none of them can be hit; a block whose box no lane's half-line reaches is not scanned.  Slab test with
+    // the box grown by 2^-9 |o - T| for this ray (see the launcher: the exact test's tolerance).  A plane's parameter is
+    // (plane - o) / d, difference first: with d_k = 0 that is -inf or +inf on the right side of the origin (a product
+    // minus a product would be inf - inf there), and not a number only for an origin exactly in a plane of the grown
+    // box, where no sphere of the block is within reach.  minNum / maxNum drop what is not a number.
+    V3 inv = v3(0.0f, 0.0f, 0.0f), o_lo = v3(0.0f, 0.0f, 0.0f), o_hi = v3(0.0f, 0.0f, 0.0f);
+    if (BOXES && tile.box) {
+        inv = v3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
+        const float grow = __builtin_amdgcn_sqrtf(vdot(op, op)) * (0x1p-9f * (1.0f + 0x1p-10f));
+        o_lo = v3(op.x + grow, op.y + grow, op.z + grow);           // lower planes move down by `grow`: plane - (o + grow)
+        o_hi = v3(op.x - grow, op.y - grow, op.z - grow);
+    }
     uint32_t blk = 0u;
     for (; blk + 32u <= count; blk += 32u) {                           // full blocks: one address, constant offsets
+        if (BOXES && tile.box) {
+            const float4 lo = tile.box[blk >> 4], hi = tile.box[(blk >> 4) + 1u];
+            const float ax = (lo.x - o_lo.x) * inv.x, bx = (hi.x - o_hi.x) * inv.x;
+            const float ay = (lo.y - o_lo.y) * inv.y, by = (hi.y - o_hi.y) * inv.y;
+            const float az = (lo.z - o_lo.z) * inv.z, bz = (hi.z - o_hi.z) * inv.z;
+            const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
+            const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+#ifdef RT_BOXCHECK   // diagnostics: a lane whose ray misses the box but whose exact test accepts a sphere of the block
+            if (tf < tn) {
+                for (uint32_t j = 0; j < 32u; j++) {
+                    const float4 e = tile.exa[blk + j];
+                    float hh, nn, dd;
+                    sphere_terms(e.x, e.y, e.z, e.w, o, d, a, hh, nn, dd);
+                    Best tmp; tmp.t = INFINITY; tmp.idx = -1;
+                    accept_exact(hh, nn, dd, a, t_min, (int)(blk + j), tile.orig, tmp);
+                    if (tmp.idx >= 0 && rt_dbg_ptr) {
+                        float* w = reinterpret_cast<float*>(rt_dbg_ptr + 1);
+                        w[0] = o.x; w[1] = o.y; w[2] = o.z; w[3] = d.x; w[4] = d.y; w[5] = d.z;
+                        w[6] = (float)(blk + j); w[7] = tmp.t; w[8] = tn; w[9] = tf; w[10] = lo.x; w[11] = lo.y; w[12] = lo.z;
+                        w[13] = hi.x; w[16] = hi.y; w[17] = hi.z; w[18] = 0.0f; w[19] = T.x; w[20] = T.y; w[21] = T.z;
+                    }
+                }
+            }
+#endif
+            if (__ballot(!(tf < tn)) == 0ull) continue;                // (anything that is not a number reaches the box)
+        }
         uint32_t miss = 0u;                                            // bit j set: sphere blk + (31-j) cannot be hit
 #pragma unroll
         for (uint32_t i = 0; i < 32u; i += RT_SCAN_UNROLL) filter_step<HALF, RT_SCAN_UNROLL>(r, tile.geo + blk + i, miss);
@@ -670,11 +720,11 @@ extern __shared__ float4 rt_lds[];
 RT_DEV uint32_t tile_capacity(const RtLaunch& L) { return L.n_padded < RT_TILE_SPHERES ? L.n_padded : RT_TILE_SPHERES; }
 
 RT_DEV Tile stage_tile(const RtLaunch& L, const float4* __restrict__ geom, const float4* __restrict__ exact,
-                       uint32_t first, uint32_t count) {
+                       const uint32_t* __restrict__ orig, uint32_t first, uint32_t count) {
     float4* geo = rt_lds;
     float4* exa = rt_lds + tile_capacity(L);
     for (uint32_t i = threadIdx.x; i < count; i += blockDim.x) { geo[i] = geom[first + i]; exa[i] = exact[first + i]; }
-    Tile t = {geo, exa};
+    Tile t = {geo, exa, nullptr, orig};
     return t;
 }
 
@@ -803,13 +853,13 @@ RT_DEV void render_body(const Scene& sc, uint32_t* __restrict__ rgba, float4* __
     const uint32_t n_items = L.max_depth > 0u ? P * L.n_chunks : 0u;   // per unit
     const bool exact_sum = L.n_chunks > 1u;
 
-    Tile tile = {rt_lds, rt_lds + tile_capacity(L)};
+    Tile tile = {rt_lds, rt_lds + tile_capacity(L), nullptr, sc.mat + L.n_padded};
     const V3 T = ld3(L.translate);
     // per wavefront and slot: [P][3] 64-bit words, fixed-point sums (exact_sum) or the fp32 run sum bits
     unsigned long long* accum = accum_base(L) + wave * (6u * P);
     for (uint32_t k = lane; k < 6u * P; k += 64u) accum[k] = 0ull;
     if (!MULTI) {
-        tile = stage_tile(L, sc.geom, sc.exact, 0u, L.n_padded);
+        tile = stage_tile(L, sc.geom, sc.exact, sc.mat + L.n_padded, 0u, L.n_padded);
         __syncthreads();
     }
 
@@ -909,7 +959,7 @@ RT_DEV void render_body(const Scene& sc, uint32_t* __restrict__ rgba, float4* __
                 uint32_t count = L.n_padded - first;
                 if (count > RT_TILE_SPHERES) count = RT_TILE_SPHERES;
                 if (first) __syncthreads();                      // previous tile fully scanned
-                tile = stage_tile(L, sc.geom, sc.exact, first, count);
+                tile = stage_tile(L, sc.geom, sc.exact, sc.mat + L.n_padded, first, count);
                 __syncthreads();
                 if (active) scan_tile<false>(tile, count, (int)first, T, L.scan_scale, o, d, a, L.t_min, b, cand, st);
             }
@@ -1006,7 +1056,7 @@ RT_DEV void render_body(const Scene& sc, uint32_t* __restrict__ rgba, float4* __
 // scattered rays of the hits in LDS.  The loop of render_body then runs on bounce segments only: a lane
 // whose path has ended takes the next queued ray; when the queue is empty the next batch of camera rays
 // of the unit is traced.  Image and segment count are those of render_body with sample_chunk = 1, bit for bit.
-//   LDS: [geo S float4][geo0 S float4: this launch's camera-ray terms, see rt_camera_terms] then per wavefront
+//   LDS: [geo S float4][geo0 S float4: this launch's camera-ray terms, see rt_camera_terms][block boxes 2 x L.scan_blocks float4] then per wavefront
 //        [candidate lists RT_Q_CAND_CAP x 64 u16][accumulators 2 x P x 3 u64][queue RT_Q_WORDS x 64 u32]
 // RT_Q_WORDS (rt_device.h) = 8 words per queued ray: origin xyz, direction xyz, sample,
 // (slot * 64 + pixel of unit) << 16 | sphere hit
@@ -1159,7 +1209,8 @@ RT_DEV void primary_batch(const Scene& sc, const Tile& tile, const float4* __res
     completed = (uint32_t)__popcll(__ballot(done));
 }
 
-template <bool FOLD>
+// BOXES: built with the blocks' bounding boxes in the bounce scan (they cost registers also where a launch has none).
+template <bool FOLD, bool BOXES>
 RT_DEV void render_queue_body(const Scene& sc, uint32_t* __restrict__ rgba, float4* __restrict__ linear,
                               unsigned long long* __restrict__ segments, uint32_t* __restrict__ work,
                               float4* __restrict__ fold_all, const float4* __restrict__ camterms, const RtCamera& cam,
@@ -1175,7 +1226,8 @@ RT_DEV void render_queue_body(const Scene& sc, uint32_t* __restrict__ rgba, floa
 
     float4* geo = rt_lds;
     float4* geo0 = rt_lds + S;
-    char* mine = reinterpret_cast<char*>(geo0 + S) + wave * (RT_Q_CAND_CAP * 128u + 48u * P + RT_Q_WORDS * 256u + RT_UL_BYTES(L.ulist_cap));
+    float4* box = geo0 + S;                                       // the blocks' boxes (scan_tile), 2 x L.scan_blocks
+    char* mine = reinterpret_cast<char*>(box + 2u * L.scan_blocks) + wave * (RT_Q_CAND_CAP * 128u + 48u * P + RT_Q_WORDS * 256u + RT_UL_BYTES(L.ulist_cap));
     Cand cand;
     cand.col = reinterpret_cast<uint16_t*>(mine) + lane;
     cand.n = 0u;
@@ -1196,10 +1248,11 @@ RT_DEV void render_queue_body(const Scene& sc, uint32_t* __restrict__ rgba, floa
         geo[i] = sc.geom[i];
         geo0[i] = camterms[i];
     }
+    for (uint32_t i = threadIdx.x; i < 2u * L.scan_blocks; i += blockDim.x) box[i] = sc.geom[S + i];
     __syncthreads();
     // the exact-test data stays in global memory (8 KB, read a couple of times per ray, cached): with it in LDS
     // a compute unit holds four workgroups instead of five, measured 2 % slower on the 485-sphere scene
-    const Tile tile = {geo, sc.exact};
+    const Tile tile = {geo, sc.exact, L.scan_blocks ? box : nullptr, sc.mat + L.n_padded};
 
     Stats st;
     Slot u0, u1;
@@ -1276,7 +1329,7 @@ RT_DEV void render_queue_body(const Scene& sc, uint32_t* __restrict__ rgba, floa
             Best b;
             b.t = L.t_max;
             b.idx = -1;
-            scan_tile<true>(tile, S, 0, T, L.scan_scale, p.o, p.d, vdot(p.d, p.d), L.t_min, b, cand, st);
+            scan_tile<true, BOXES>(tile, S, 0, T, L.scan_scale, p.o, p.d, vdot(p.d, p.d), L.t_min, b, cand, st);
             nseg++;
             V3 color;
             if (shade_segment(sc, L, seed, b, pixel, s, band, p, color, st)) {
@@ -1321,7 +1374,7 @@ RT_DEV void render_queue_body(const Scene& sc, uint32_t* __restrict__ rgba, floa
 //        entries of the unit's list (unit_list; RT_UL_NONE: none)
 //   ctl: [0] slot the camera rays are taken from (POOL_NONE before the first unit, POOL_DRAINED when the launch's
 //        counter has run out), [1] lock of the wavefront that is opening a unit
-//   LDS: [geo S float4][geo0 S float4][slots NS x 8 u32][ctl 4 u32][accumulators NS x P x 3 u64][unit lists NS x
+//   LDS: [geo S float4][geo0 S float4][block boxes 2 x L.scan_blocks float4][slots NS x 8 u32][ctl 4 u32][accumulators NS x P x 3 u64][unit lists NS x
 //        RT_UL_BYTES] then per wavefront [candidate lists RT_Q_CAND_CAP x 64 u16][queue RT_Q_WORDS x 64 u32]
 // A finished sample is added to its pixel's accumulators and then taken off its slot's count (LDS operations of a
 // wavefront are performed in order); whoever takes the last one off writes the unit's pixels and frees the slot.
@@ -1336,7 +1389,7 @@ RT_DEV void render_queue_body(const Scene& sc, uint32_t* __restrict__ rgba, floa
 // Returns true if it makes sense to look at the control word again right away.
 // The list of pool slot `slot` (the workgroup's LDS layout: see render_pool_body).
 RT_DEV UnitList pool_list(const RtLaunch& L, uint32_t slot) {
-    char* base = reinterpret_cast<char*>(rt_lds + 2u * L.n_padded) + L.pool_slots * (32u + 24u * L.unit_w * L.unit_h) + 16u;
+    char* base = reinterpret_cast<char*>(rt_lds + 2u * L.n_padded + 2u * L.scan_blocks) + L.pool_slots * (32u + 24u * L.unit_w * L.unit_h) + 16u;
     UnitList ul;
     ul.terms = reinterpret_cast<float4*>(base + slot * RT_UL_BYTES(L.ulist_cap));
     ul.idx = reinterpret_cast<uint16_t*>(ul.terms + L.ulist_cap);
@@ -1475,7 +1528,9 @@ RT_DEV void pool_finish(const RtLaunch& L, uint32_t* slots, unsigned long long* 
     if (uniform_u32(old) == n) pool_write(L, slots, accum, sl, lane, rgba, linear, fold);
 }
 
-template <bool FOLD, bool LISTS>
+// LISTS, BOXES: built with the pixel units' sphere lists / the blocks' bounding boxes in the bounce scan (both cost
+// registers also where a launch has none).
+template <bool FOLD, bool LISTS, bool BOXES>
 RT_DEV void render_pool_body(const Scene& sc, uint32_t* __restrict__ rgba, float4* __restrict__ linear,
                              unsigned long long* __restrict__ segments, uint32_t* __restrict__ work,
                              float4* __restrict__ fold_all, const float4* __restrict__ camterms, const RtCamera& cam,
@@ -1490,7 +1545,8 @@ RT_DEV void render_pool_body(const Scene& sc, uint32_t* __restrict__ rgba, float
 
     float4* geo = rt_lds;
     float4* geo0 = rt_lds + S;
-    uint32_t* slots = reinterpret_cast<uint32_t*>(geo0 + S);
+    float4* box = geo0 + S;                                       // the blocks' boxes (scan_tile), 2 x L.scan_blocks
+    uint32_t* slots = reinterpret_cast<uint32_t*>(box + 2u * L.scan_blocks);
     uint32_t* ctl = slots + NS * 8u;
     unsigned long long* accum = reinterpret_cast<unsigned long long*>(ctl + 4u);
     char* mine = reinterpret_cast<char*>(accum + NS * 3u * P) + NS * RT_UL_BYTES(L.ulist_cap) + wave * (RT_Q_CAND_CAP * 128u + RT_Q_WORDS * 256u);
@@ -1508,8 +1564,9 @@ RT_DEV void render_pool_body(const Scene& sc, uint32_t* __restrict__ rgba, float
         geo[i] = sc.geom[i];
         geo0[i] = camterms[i];
     }
+    for (uint32_t i = threadIdx.x; i < 2u * L.scan_blocks; i += blockDim.x) box[i] = sc.geom[S + i];
     __syncthreads();
-    const Tile tile = {geo, sc.exact};
+    const Tile tile = {geo, sc.exact, L.scan_blocks ? box : nullptr, sc.mat + L.n_padded};
 
     Stats st;
     bool drained = false;
@@ -1590,7 +1647,7 @@ RT_DEV void render_pool_body(const Scene& sc, uint32_t* __restrict__ rgba, float
             Best b;
             b.t = L.t_max;
             b.idx = -1;
-            scan_tile<true>(tile, S, 0, T, L.scan_scale, p.o, p.d, vdot(p.d, p.d), L.t_min, b, cand, st);
+            scan_tile<true, BOXES>(tile, S, 0, T, L.scan_scale, p.o, p.d, vdot(p.d, p.d), L.t_min, b, cand, st);
             nseg++;
             V3 color;
             if (shade_segment(sc, L, seed, b, pixel, s, band, p, color, st)) {
@@ -1663,7 +1720,9 @@ RT_DEV void render_queue_stream_body(const Scene& sc, uint32_t* __restrict__ rgb
 
     float4* geo = rt_lds;
     float4* geo0 = rt_lds + S;
-    char* mine = reinterpret_cast<char*>(geo0 + S) + wave * (RT_Q_CAND_CAP * 128u + 48u * P + RT_Q_WORDS * 256u + RT_UL_BYTES(L.ulist_cap));
+    float4* box = geo0 + S;                                       // the boxes of the tile's blocks (scan_tile), 2 x S / 32
+    const uint32_t box_f4 = L.scan_blocks ? 2u * (S / 32u) : 0u;
+    char* mine = reinterpret_cast<char*>(box + box_f4) + wave * (RT_Q_CAND_CAP * 128u + 48u * P + RT_Q_WORDS * 256u + RT_UL_BYTES(L.ulist_cap));
     Cand cand;
     cand.col = reinterpret_cast<uint16_t*>(mine) + lane;
     cand.n = 0u;
@@ -1676,7 +1735,7 @@ RT_DEV void render_queue_stream_body(const Scene& sc, uint32_t* __restrict__ rgb
     ul.terms = reinterpret_cast<float4*>(mine + RT_Q_CAND_CAP * 128u + 48u * P + RT_Q_WORDS * 256u);
     ul.idx = reinterpret_cast<uint16_t*>(ul.terms + L.ulist_cap);
     uint32_t ul_k = RT_UL_NONE;
-    const Tile whole = {geo, sc.exact};                           // exact-test data of the whole list, by sphere index
+    const Tile whole = {geo, sc.exact, nullptr, sc.mat + L.n_padded};                           // exact-test data of the whole list, by sphere index
     for (uint32_t k = lane; k < 6u * P; k += 64u) accum[k] = 0ull;
     float4* fold = FOLD ? fold_all + (size_t)(blockIdx.x * (blockDim.x >> 6) + wave) * (2u * P * (size_t)L.samples_per_pixel) : nullptr;
     const float4* fold1 = FOLD ? fold + (size_t)P * L.samples_per_pixel : nullptr;
@@ -1774,8 +1833,11 @@ RT_DEV void render_queue_stream_body(const Scene& sc, uint32_t* __restrict__ rgb
                     geo[i] = sc.geom[first + i];
                     geo0[i] = camterms[first + i];
                 }
+                // (every wavefront stages its share of the tile and of the blocks' boxes, whichever sweep it is in)
+                for (uint32_t i = threadIdx.x; i < box_f4 && first / 16u + i < 2u * L.scan_blocks; i += blockDim.x)
+                    box[i] = sc.geom[L.n_padded + first / 16u + i];
                 __syncthreads();
-                const Tile tile = {geo, sc.exact + first};       // exact-test data from global memory
+                const Tile tile = {geo, sc.exact + first, nullptr, sc.mat + L.n_padded};   // exact-test data from global memory
                 if (traced) {
                     scan_primary(geo0, nullptr, tile, count, (int)first, bfx, bfy, co, bd, ba, L.t_min, b, cand, st);
 #ifdef RT_EXP_PRIMARY2
@@ -1817,9 +1879,11 @@ RT_DEV void render_queue_stream_body(const Scene& sc, uint32_t* __restrict__ rgb
                     geo[i] = sc.geom[first + i];
                     geo0[i] = camterms[first + i];
                 }
+                for (uint32_t i = threadIdx.x; i < box_f4 && first / 16u + i < 2u * L.scan_blocks; i += blockDim.x)
+                    box[i] = sc.geom[L.n_padded + first / 16u + i];          // (2 float4 per 32 spheres)
                 __syncthreads();
-                const Tile tile = {geo, sc.exact + first};       // exact-test data from global memory
-                if (active) scan_tile<true>(tile, count, (int)first, T, L.scan_scale, p.o, p.d, ra, L.t_min, b, cand, st);
+                const Tile tile = {geo, sc.exact + first, box_f4 ? box : nullptr, sc.mat + L.n_padded};   // exact-test data from global memory
+                if (active) scan_tile<true, true>(tile, count, (int)first, T, L.scan_scale, p.o, p.d, ra, L.t_min, b, cand, st);
             }
             if (active) {
                 nseg++;
@@ -1852,6 +1916,7 @@ rt_render(const float4* geom, const float4* exact, const float4* shade, const ui
           float4* linear, unsigned long long* segments, uint32_t* work, float4* fold, const float4* camterms,
           RtCamera cam, RtLaunch L) {
     Scene sc = {geom, exact, shade, mat};
+    RT_DBG_SET(segments);
     render_body<false>(sc, rgba, linear, segments, work, cam, L);
 }
 
@@ -1863,7 +1928,19 @@ rt_render_queue(const float4* geom, const float4* exact, const float4* shade, co
                 float4* linear, unsigned long long* segments, uint32_t* work, float4* fold, const float4* camterms,
                 RtCamera cam, RtLaunch L) {
     Scene sc = {geom, exact, shade, mat};
-    render_queue_body<false>(sc, rgba, linear, segments, work, fold, camterms, cam, L);
+    RT_DBG_SET(segments);
+    render_queue_body<false, false>(sc, rgba, linear, segments, work, fold, camterms, cam, L);
+}
+
+// rt_render_queue built with the blocks' bounding boxes in the bounce scan, for scenes whose sphere list the launcher
+// sorted in space (128 spheres and more): on the 485-sphere book scene two thirds of the blocks are not scanned.
+extern "C" __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6)))
+rt_render_queue_boxes(const float4* geom, const float4* exact, const float4* shade, const uint32_t* mat, uint32_t* rgba,
+                      float4* linear, unsigned long long* segments, uint32_t* work, float4* fold, const float4* camterms,
+                      RtCamera cam, RtLaunch L) {
+    Scene sc = {geom, exact, shade, mat};
+    RT_DBG_SET(segments);
+    render_queue_body<false, true>(sc, rgba, linear, segments, work, fold, camterms, cam, L);
 }
 
 extern "C" __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(5)))
@@ -1871,6 +1948,7 @@ rt_render_queue_stream(const float4* geom, const float4* exact, const float4* sh
                        float4* linear, unsigned long long* segments, uint32_t* work, float4* fold, const float4* camterms,
                        RtCamera cam, RtLaunch L) {
     Scene sc = {geom, exact, shade, mat};
+    RT_DBG_SET(segments);
     render_queue_stream_body<false>(sc, rgba, linear, segments, work, fold, camterms, cam, L);
 }
 
@@ -1880,7 +1958,18 @@ rt_render_pool(const float4* geom, const float4* exact, const float4* shade, con
                float4* linear, unsigned long long* segments, uint32_t* work, float4* fold, const float4* camterms,
                RtCamera cam, RtLaunch L) {
     Scene sc = {geom, exact, shade, mat};
-    render_pool_body<false, true>(sc, rgba, linear, segments, work, nullptr, camterms, cam, L);
+    RT_DBG_SET(segments);
+    render_pool_body<false, true, false>(sc, rgba, linear, segments, work, nullptr, camterms, cam, L);
+}
+
+// rt_render_pool with the blocks' bounding boxes in the bounce scan (scenes sorted in space, as rt_render_queue_boxes).
+extern "C" __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6)))
+rt_render_pool_boxes(const float4* geom, const float4* exact, const float4* shade, const uint32_t* mat, uint32_t* rgba,
+                     float4* linear, unsigned long long* segments, uint32_t* work, float4* fold, const float4* camterms,
+                     RtCamera cam, RtLaunch L) {
+    Scene sc = {geom, exact, shade, mat};
+    RT_DBG_SET(segments);
+    render_pool_body<false, true, true>(sc, rgba, linear, segments, work, nullptr, camterms, cam, L);
 }
 
 // rt_render_pool built without the pixel units' sphere lists, for the launches that have none (scenes of a handful of
@@ -1891,7 +1980,8 @@ rt_render_pool_plain(const float4* geom, const float4* exact, const float4* shad
                      float4* linear, unsigned long long* segments, uint32_t* work, float4* fold, const float4* camterms,
                      RtCamera cam, RtLaunch L) {
     Scene sc = {geom, exact, shade, mat};
-    render_pool_body<false, false>(sc, rgba, linear, segments, work, nullptr, camterms, cam, L);
+    RT_DBG_SET(segments);
+    render_pool_body<false, false, false>(sc, rgba, linear, segments, work, nullptr, camterms, cam, L);
 }
 
 // The same two kernels in fold-order mode (RtParams.sample_chunk = 0): finished samples are parked in the
@@ -1902,7 +1992,8 @@ rt_render_queue_fold(const float4* geom, const float4* exact, const float4* shad
                      float4* linear, unsigned long long* segments, uint32_t* work, float4* fold, const float4* camterms,
                      RtCamera cam, RtLaunch L) {
     Scene sc = {geom, exact, shade, mat};
-    render_queue_body<true>(sc, rgba, linear, segments, work, fold, camterms, cam, L);
+    RT_DBG_SET(segments);
+    render_queue_body<true, true>(sc, rgba, linear, segments, work, fold, camterms, cam, L);
 }
 
 // rt_render_pool in fold-order mode: finished samples go to the workgroup's part of the workspace.
@@ -1911,7 +2002,8 @@ rt_render_pool_fold(const float4* geom, const float4* exact, const float4* shade
                     float4* linear, unsigned long long* segments, uint32_t* work, float4* fold, const float4* camterms,
                     RtCamera cam, RtLaunch L) {
     Scene sc = {geom, exact, shade, mat};
-    render_pool_body<true, true>(sc, rgba, linear, segments, work, fold, camterms, cam, L);
+    RT_DBG_SET(segments);
+    render_pool_body<true, true, true>(sc, rgba, linear, segments, work, fold, camterms, cam, L);
 }
 
 extern "C" __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(5)))
@@ -1919,6 +2011,7 @@ rt_render_queue_stream_fold(const float4* geom, const float4* exact, const float
                             float4* linear, unsigned long long* segments, uint32_t* work, float4* fold, const float4* camterms,
                             RtCamera cam, RtLaunch L) {
     Scene sc = {geom, exact, shade, mat};
+    RT_DBG_SET(segments);
     render_queue_stream_body<true>(sc, rgba, linear, segments, work, fold, camterms, cam, L);
 }
 
@@ -1927,6 +2020,7 @@ rt_render_stream(const float4* geom, const float4* exact, const float4* shade, c
                  float4* linear, unsigned long long* segments, uint32_t* work, float4* fold, const float4* camterms,
                  RtCamera cam, RtLaunch L) {
     Scene sc = {geom, exact, shade, mat};
+    RT_DBG_SET(segments);
     render_body<true>(sc, rgba, linear, segments, work, cam, L);
 }
 
@@ -2032,7 +2126,7 @@ rt_camera_terms(const float4* __restrict__ exact, float4* __restrict__ camterms,
 // ---------------------------------------------------------------- primary-hit index map
 // Closest sphere index (or -1) of the ray through each pixel centre (sub-pixel offset 0).
 extern "C" __global__ void __launch_bounds__(1024)
-rt_primary_hits(const float4* geom, const float4* exact, int32_t* hits, RtCamera cam, RtLaunch L) {
+rt_primary_hits(const float4* geom, const float4* exact, const uint32_t* mat, int32_t* hits, RtCamera cam, RtLaunch L) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave_tile = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     uint32_t x, ly, y;
@@ -2050,11 +2144,11 @@ rt_primary_hits(const float4* geom, const float4* exact, int32_t* hits, RtCamera
         uint32_t count = L.n_padded - first;
         if (count > RT_TILE_SPHERES) count = RT_TILE_SPHERES;
         if (first) __syncthreads();
-        Tile tile = stage_tile(L, geom, exact, first, count);
+        Tile tile = stage_tile(L, geom, exact, mat + L.n_padded, first, count);
         __syncthreads();
         if (valid) scan_tile<false>(tile, count, (int)first, ld3(L.translate), L.scan_scale, o, d, a, L.t_min, b, cand, st);
     }
-    if (valid) hits[(size_t)ly * L.width + x] = b.idx;
+    if (valid) hits[(size_t)ly * L.width + x] = b.idx < 0 ? -1 : (int32_t)mat[L.n_padded + (uint32_t)b.idx];   // the caller's index
 }
 
 // ---------------------------------------------------------------- RNG debug views (ray.cu:114-118)

@@ -19,12 +19,20 @@ def rt():
 
 
 # The pooled kernel has a build without the pixel units' sphere lists, run where a launch has none (fewer than 16
-# spheres, or no room in LDS beside 64-pixel units): which of the two runs is not what most tests here are about.
-POOLED = ("rt_render_pool", "rt_render_pool_plain")
+# spheres, or no room in LDS beside 64-pixel units), and one with the blocks' bounding boxes in its bounce scan (scenes
+# of 128 spheres and more): which of them runs is not what most tests here are about.
+POOLED = ("rt_render_pool", "rt_render_pool_plain", "rt_render_pool_boxes")
+
+
+# ... and the per-wavefront kernel a build with the blocks' bounding boxes in its bounce scan, run on scenes of 128
+# spheres and more (the launcher sorts those in space).
+WAVE = ("rt_render_queue", "rt_render_queue_boxes")
 
 
 def same_kernel(name, expected):
-    return name in POOLED if expected == "rt_render_pool" else name == expected
+    if expected == "rt_render_pool":
+        return name in POOLED
+    return name in WAVE if expected == "rt_render_queue" else name == expected
 
 
 @pytest.fixture(scope="module")
@@ -196,7 +204,7 @@ def test_c2_full_size(oracle, rt, hip):
     hip.debug_schedule(scheduler="wave")
     other = hip.render(cam, p, linear=True)
     hip.debug_schedule()
-    assert hip.last_kernel_name() == "rt_render_queue"
+    assert hip.last_kernel_name() in WAVE
     assert np.array_equal(other["linear"].view(np.uint32), full["linear"].view(np.uint32)) and other["rays"] == full["rays"]
 
 
@@ -354,7 +362,7 @@ def test_camera_ray_batches_edge_cases(oracle, rt, hip):
     # depth 0 traces nothing: no pool to run
     hip.debug_schedule(scheduler="pool")
     hip.render(cam, rt.DeviceGUI(samples_per_pixel=6, max_depth=0, sample_chunk=1))
-    assert hip.last_kernel_name() == "rt_render_queue"
+    assert hip.last_kernel_name() in WAVE
     hip.debug_schedule()
     with pytest.raises(rt.RtError):
         hip._check(hip._lib.rt_debug_schedule(hip._ctx, 0, 0, 0, 7))
@@ -656,6 +664,75 @@ def test_pixel_unit_sphere_lists_change_nothing_but_the_time(rt, hip, monkeypatc
                     assert ms[0] < 0.95 * ms[1], (sched, ms)
 
 
+def test_sorted_sphere_list_and_block_boxes_change_nothing(rt, monkeypatch):
+    """Scenes of 128 spheres and more are sorted in space at upload and the bounce scan skips blocks of 32 spheres
+    whose bounding box no lane's ray reaches (scan_tile).  The full-size frames -- book scene 4K at 500 spp (twelve
+    thousand million segments, among them some thirty whose two nearest spheres report the very same root: ties go to
+    the caller's earlier sphere, whatever the device order) and the 16,385-sphere grid -- are the same bit for bit,
+    segment count included, as with the list left in the caller's order (RT_EXP_NO_SORT, read at upload)."""
+    cases = [(rt.scene_book1_final(1), rt.Camera.look_at(16.0 / 9.0, 3840, 20.0, (13.0, 2.0, 3.0), (0.0, 0.0, 0.0)), 500, 50, "rt_render_queue_boxes"),
+             (rt.scene_grid(2, 128), rt.Camera.look_at(16.0 / 9.0, 1920, 40.0, (0.0, 30.0, 80.0), (0.0, 0.0, 0.0)), 64, 16, "rt_render_queue_stream")]
+    for sp, cam, spp, depth, kernel in cases:
+        p = rt.DeviceGUI(samples_per_pixel=spp, max_depth=depth, seed=1, sample_chunk=1)
+        frames = []
+        for unsorted in (False, True):
+            if unsorted:
+                monkeypatch.setenv("RT_EXP_NO_SORT", "1")
+            with rt.HipWorld(0, sp) as w:
+                w.debug_schedule(scheduler="wave")
+                frames.append(w.render(cam, p, linear=True))
+                assert w.last_kernel_name() == (kernel if not unsorted else kernel.replace("_boxes", ""))
+            monkeypatch.delenv("RT_EXP_NO_SORT", raising=False)
+        assert frames[0]["rays"] == frames[1]["rays"]
+        assert np.array_equal(frames[0]["linear"].view(np.uint32), frames[1]["linear"].view(np.uint32))
+        assert frames[0]["kernel_ms"] < 0.85 * frames[1]["kernel_ms"], (frames[0]["kernel_ms"], frames[1]["kernel_ms"])
+
+
+def test_block_boxes_never_exclude_a_sphere_the_exact_test_accepts(rt):
+    """The diagnostics build of the kernels (-DRT_BOXCHECK): a lane whose ray misses a block's box runs the exact test
+    on the block's 32 spheres all the same and records the ray if one of them is accepted.  Nothing is recorded on the
+    book scene (per-wavefront, pooled and fold kernels), the grid (streamed list), a cloud of overlapping spheres with
+    rays starting inside them, a scene far from the origin and one with a ground sphere."""
+    import os
+    import struct
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ray_tracing_amd", "csrc", "rt_kernels_x_boxcheck.hsaco")
+    if not os.path.exists(path):
+        pytest.skip("diagnostics code object not built (make -C ray_tracing_amd/csrc experiments)")
+    rng = np.random.default_rng(77)
+
+    def cloud(n, shift=0.0, ground=False):
+        sp = np.zeros(n, rt.SPHERE_DTYPE)
+        sp["center"] = (rng.uniform(-6, 6, (n, 3)) + shift).astype(np.float32)
+        sp["radius"] = np.exp(rng.uniform(np.log(0.05), np.log(3.0), n)).astype(np.float32)
+        if ground:
+            sp["center"][0] = (shift, shift - 1000.0, shift); sp["radius"][0] = 1000.0
+        sp["material"] = rng.choice([1, 2, 3], n, p=[0.5, 0.3, 0.2])
+        sp["albedo"] = rng.uniform(0.1, 1.0, (n, 3)).astype(np.float32)
+        sp["param"] = np.where(sp["material"] == 3, 1.5, rng.uniform(0.0, 1.0, n)).astype(np.float32)
+        return sp
+
+    scenes = [(rt.scene_book1_final(1), rt.Camera.look_at(16.0 / 9.0, 480, 20.0, (13.0, 2.0, 3.0), (0.0, 0.0, 0.0)), 64, 50),
+              (rt.scene_grid(2, 48), rt.Camera.look_at(16.0 / 9.0, 320, 40.0, (0.0, 12.0, 30.0), (0.0, 0.0, 0.0)), 16, 16),
+              (cloud(200), rt.Camera.look_at(1.0, 160, 60.0, (7.0, 3.0, 8.0), (0.0, 0.0, 0.0)), 16, 30),
+              (cloud(1030, ground=True), rt.Camera.look_at(1.0, 160, 60.0, (7.0, 3.0, 8.0), (0.0, 0.0, 0.0)), 8, 30),
+              (cloud(300, shift=5000.0), rt.Camera.look_at(1.0, 160, 60.0, (5007.0, 5003.0, 5008.0), (5000.0, 5000.0, 5000.0)), 16, 30)]
+    with rt.HipWorld(0) as w:
+        w.load_module(open(path, "rb").read())
+        ran = set()
+        for sp, cam, spp, depth in scenes:
+            w.upload_scene(sp)
+            for chunk, scheds in ((1, ("wave", "pool")), (0, ("wave", "pool"))):
+                for sched in scheds:
+                    w.debug_schedule(scheduler=sched)
+                    w.render(cam, rt.DeviceGUI(samples_per_pixel=spp, max_depth=depth, seed=3, sample_chunk=chunk))
+                    w.debug_schedule()
+                    ran.add(w.last_kernel_name())
+                    words = np.frombuffer(b"".join(struct.pack("<Q", int(v)) for v in w.debug_counters()), np.float32)[2:]
+                    # (words 14 and 15 of the block are the launch's unit counter)
+                    assert not words[:14].any(), (w.last_kernel_name(), len(sp), "ray o, d, sphere, root, box interval:", words[:10].tolist())
+        assert {"rt_render_queue_boxes", "rt_render_pool_boxes", "rt_render_queue_stream", "rt_render_queue_fold", "rt_render_pool_fold"} <= ran, ran
+
+
 def test_scheduler_is_chosen_by_launch_size_and_does_not_change_the_image(rt, hip):
     """With every sample its own item the library pools the pixel units per workgroup on short launches (an estimate of the
     launch's work per resident wavefront, rt_hip.cpp make_launch) and leaves them with the wavefronts on larger ones (the crossover itself is timed on
@@ -673,7 +750,7 @@ def test_scheduler_is_chosen_by_launch_size_and_does_not_change_the_image(rt, hi
     assert hip.last_kernel_name() in POOLED
     hip.debug_schedule(unit=(1, 1), scheduler="wave")
     large = hip.render(cam, p, linear=True)
-    assert hip.last_kernel_name() == "rt_render_queue"
+    assert hip.last_kernel_name() in WAVE
     hip.debug_schedule()
     assert np.array_equal(small["linear"], large["linear"]) and small["rays"] == large["rays"]
     for block in (64, 128, 320, 1024):
