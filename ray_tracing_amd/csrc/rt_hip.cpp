@@ -408,9 +408,9 @@ int launch_render(rt_ctx* c, const RtCamera* cam, const RtParams* p, RtLaunch L,
             waves = block / 64u;
             grid = (L.n_units + waves - 1u) / waves;
         }
-        // the unit lists are the first thing to go where a workgroup's LDS (64 KiB) is short: 16 entries, 8, none
+        // the unit lists are the first thing to go where a workgroup's LDS (64 KiB) is short: 16 entries, 12, 8, none
         auto queue_lds = [&](unsigned cap) {
-            return (one_tile ? c->n_padded * 32u + L.scan_blocks * 32u : RT_Q_STREAM_TILE * 32u + (L.scan_blocks ? RT_Q_STREAM_TILE : 0u)) +
+            return (one_tile ? c->n_padded * 32u + L.scan_blocks * 32u : RT_Q_STREAM_TILE * 32u + (L.scan_blocks ? RT_Q_STREAM_TILE + 32u : 0u)) +
                    waves * (RT_Q_CAND_CAP * 128u + 48u * P + RT_Q_WORDS * 256u + RT_UL_BYTES(cap));
         };
         auto pool_lds = [&](unsigned cap) {
@@ -423,7 +423,7 @@ int launch_render(rt_ctx* c, const RtCamera* cam, const RtParams* p, RtLaunch L,
         const char* pool_name = nullptr;
         if (L.pool_slots != 0u) {
             // the boxes and the lists are the first things to go where a workgroup's LDS (64 KiB) is short
-            while (L.ulist_cap != 0u && pool_lds(L.ulist_cap) > 65536u) L.ulist_cap = L.ulist_cap > 8u ? 8u : 0u;
+            while (L.ulist_cap != 0u && pool_lds(L.ulist_cap) > 65536u) L.ulist_cap = L.ulist_cap > 12u ? 12u : L.ulist_cap > 8u ? 8u : 0u;
             if (pool_lds(0u) > 65536u) L.scan_blocks = 0u;
             if (L.fold) { pool_f = c->f_render_pool_fold; pool_name = "rt_render_pool_fold"; }
             else if (L.scan_blocks != 0u && c->f_render_pool_boxes) { pool_f = c->f_render_pool_boxes; pool_name = "rt_render_pool_boxes"; }
@@ -436,10 +436,13 @@ int launch_render(rt_ctx* c, const RtCamera* cam, const RtParams* p, RtLaunch L,
                 const unsigned bytes = L.pool_slots ? pool_lds(cap) : queue_lds(cap);
                 int n = 0;
                 if (bytes > 65536u || hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&n, fq, (int)block, bytes) != hipSuccess) n = 0;
-                return n;
+                // (measured on the streaming kernel: five 256-thread workgroups are resident up to 31,648 bytes each, four
+                // from 31,776 on, where the runtime's figure still says five: 155 KiB of the 160 are to be had)
+                const int by_lds = (int)(158720u / (bytes ? bytes : 1u));
+                return n < by_lds ? n : by_lds;
             };
             const int without = resident_with(0u);
-            while (L.ulist_cap != 0u && resident_with(L.ulist_cap) < without) L.ulist_cap = L.ulist_cap > 8u ? 8u : 0u;
+            while (L.ulist_cap != 0u && resident_with(L.ulist_cap) < without) L.ulist_cap = L.ulist_cap > 12u ? 12u : L.ulist_cap > 8u ? 8u : 0u;
         }
         lds = queue_lds(L.ulist_cap);
         // Who holds the open pixel units: each wavefront two of its own (rt_render_queue), or the workgroup a pool of
@@ -470,6 +473,8 @@ int launch_render(rt_ctx* c, const RtCamera* cam, const RtParams* p, RtLaunch L,
     int resident = 0;
     RT_HIP(c, hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&resident, f, (int)block, lds));
     if (resident < 1) return fail(c, RT_ERR_INVALID, "render kernel does not fit a compute unit with this block_dim and scene");
+    if (std::getenv("RT_DEBUG_LAUNCH"))                                        // launch shape, for experiments
+        std::fprintf(stderr, "rt launch: %s block %u lds %u B resident %d per CU, units %ux%u, lists %u, blocks %u, grid %u\n", c->last_kernel, block, lds, resident, L.unit_w, L.unit_h, L.ulist_cap, L.scan_blocks, grid);
     const unsigned fill = (unsigned)resident * (unsigned)(c->compute_units > 0 ? c->compute_units : 1);
     if (grid > fill) grid = fill;
     // fold-order workspace: per wavefront of the grid, two open units x P pixels x samples_per_pixel colours
@@ -760,9 +765,10 @@ int rt_upload_scene(rt_ctx* c, const RtSphere* spheres, uint32_t n) {
     // from T: each sphere's own |r| (1 + 2^-10) + 2^-9 |c - T| + 2^-20 R beyond its centre (the kernel adds 2^-9 |o - T|
     // for its ray; the exact test's tolerance is below 2^-11 |c - o|)
     const uint32_t n_blocks = (n_padded + 31u) / 32u;
-    std::vector<float> geom(((size_t)n_padded + 2u * n_blocks) * 4), exact((size_t)n_padded * 4), shade((size_t)n_padded * 12, 0.0f);
+    const uint32_t n_tiles = (n_padded + RT_Q_STREAM_TILE - 1u) / RT_Q_STREAM_TILE;   // ... and one box per tile of the streaming kernels behind those
+    std::vector<float> geom(((size_t)n_padded + 2u * n_blocks + 2u * n_tiles) * 4), exact((size_t)n_padded * 4), shade((size_t)n_padded * 12, 0.0f);
     std::vector<uint32_t> mat((size_t)n_padded * 2u);
-    for (uint32_t b = 0; b < n_blocks; b++) {
+    for (uint32_t b = 0; b < n_blocks + n_tiles; b++) {
         float* lo4 = &geom[4 * ((size_t)n_padded + 2u * b)];
         lo4[0] = lo4[1] = lo4[2] = INFINITY; lo4[3] = 0.0f;
         lo4[4] = lo4[5] = lo4[6] = -INFINITY; lo4[7] = 0.0f;
@@ -792,6 +798,9 @@ int rt_upload_scene(rt_ctx* c, const RtSphere* spheres, uint32_t n) {
                     const float a = std::nextafter((float)((double)g[k] - ext), -INFINITY), b = std::nextafter((float)((double)g[k] + ext), INFINITY);
                     if (!(a >= lo4[k])) lo4[k] = a;                   // (a NaN sticks: the box then never excludes anything)
                     if (!(b <= lo4[4 + k])) lo4[4 + k] = b;
+                    float* t4 = &geom[4 * ((size_t)n_padded + 2u * n_blocks + 2u * (i / RT_Q_STREAM_TILE))];
+                    if (!(a >= t4[k])) t4[k] = a;
+                    if (!(b <= t4[4 + k])) t4[4 + k] = b;
                 }
             }
             x[3] = rr;
@@ -821,7 +830,7 @@ int rt_upload_scene(rt_ctx* c, const RtSphere* spheres, uint32_t n) {
         }
     }
     size_t bytes = (size_t)n_padded * 16u;
-    const size_t geom_bytes = bytes + (size_t)n_blocks * 32u;
+    const size_t geom_bytes = bytes + ((size_t)n_blocks + n_tiles) * 32u;
     void** owned[] = {&c->d_geom, &c->d_exact, &c->d_shade, &c->d_mat, &c->d_camterms};
     for (void** p : owned) if (*p) { RT_HIP(c, hipFree(*p)); *p = nullptr; }
     c->have_scene = false;

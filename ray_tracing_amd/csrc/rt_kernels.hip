@@ -185,7 +185,8 @@ RT_DEV void sphere_terms(float cx, float cy, float cz, float rr, V3 o, V3 d, flo
 //   exa[i] = {cx, cy, cz, r*r}                exact test (LDS, or global memory in the queue kernels)
 // box: two float4 per block of 32 spheres (scan_tile), or NULL; orig: the caller's index of every device sphere (the
 // whole list's, whatever the tile)
-struct Tile { const float4* geo; const float4* exa; const float4* box; const uint32_t* orig; };
+// tbox: two float4, the box around the whole tile's spheres (the kernels that stream the list), or NULL
+struct Tile { const float4* geo; const float4* exa; const float4* box; const uint32_t* orig; const float4* tbox; };
 
 // Per-lane list of candidate spheres of the tile being scanned, kept in LDS as a column of a
 // [cap][64] u16 array per wavefront (lane l owns column l, so pushes never conflict).
@@ -330,6 +331,29 @@ RT_DEV void scan_tile(const Tile& tile, uint32_t count, int base, V3 T, float si
                       V3 o, V3 d, float a, float t_min, Best& b, Cand& c, Stats& st) {
     st.wave(1);
     const V3 op = vsub(o, T);
+    // Block boxes (tile.box != NULL): the list is sorted in space and every block of 32 spheres has a box outside
+    // which none of them can be hit; a block whose box no lane's half-line reaches is not scanned.  Slab test with
+    // the box grown by 2^-9 |o - T| for this ray (see the launcher: the exact test's tolerance).  A plane's parameter is
+    // (plane - o) / d, difference first: with d_k = 0 that is -inf or +inf on the right side of the origin (a product
+    // minus a product would be inf - inf there), and not a number only for an origin exactly in a plane of the grown
+    // box, where no sphere of the block is within reach.  minNum / maxNum drop what is not a number.
+    // tile.tbox: the same test for the whole tile first (a streamed list: most tiles are out of every lane's reach).
+    V3 inv = v3(0.0f, 0.0f, 0.0f), o_lo = v3(0.0f, 0.0f, 0.0f), o_hi = v3(0.0f, 0.0f, 0.0f);
+    if (BOXES && tile.box) {
+        inv = v3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
+        const float grow = __builtin_amdgcn_sqrtf(vdot(op, op)) * (0x1p-9f * (1.0f + 0x1p-10f));
+        o_lo = v3(op.x + grow, op.y + grow, op.z + grow);           // lower planes move down by `grow`: plane - (o + grow)
+        o_hi = v3(op.x - grow, op.y - grow, op.z - grow);
+        if (tile.tbox) {
+            const float4 lo = tile.tbox[0], hi = tile.tbox[1];
+            const float ax = (lo.x - o_lo.x) * inv.x, bx = (hi.x - o_hi.x) * inv.x;
+            const float ay = (lo.y - o_lo.y) * inv.y, by = (hi.y - o_hi.y) * inv.y;
+            const float az = (lo.z - o_lo.z) * inv.z, bz = (hi.z - o_hi.z) * inv.z;
+            const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
+            const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+            if (__ballot(!(tf < tn)) == 0ull) return;                  // (the lanes' candidate lists are empty between tiles)
+        }
+    }
     const float inv_len = filter_inv_len(a) * sigma;
     const float s2 = sigma * sigma;
     RayTerms r;
@@ -337,19 +361,6 @@ RT_DEV void scan_tile(const Tile& tile, uint32_t count, int base, V3 T, float si
     r.e = -vdot(r.uf, op);
     r.w = v3((2.0f * s2) * op.x, (2.0f * s2) * op.y, (2.0f * s2) * op.z);
     r.k0 = -(vdot(op, op) * (1.0f - 0x1p-18f)) * s2;
-    // Block boxes (tile.box != NULL): the list is sorted in space and every block of 32 spheres has a box outside
-    // which none of them can be hit; a block whose box no lane's half-line reaches is not scanned.  Slab test with
-    // the box grown by 2^-9 |o - T| for this ray (see the launcher: the exact test's tolerance).  A plane's parameter is
-    // (plane - o) / d, difference first: with d_k = 0 that is -inf or +inf on the right side of the origin (a product
-    // minus a product would be inf - inf there), and not a number only for an origin exactly in a plane of the grown
-    // box, where no sphere of the block is within reach.  minNum / maxNum drop what is not a number.
-    V3 inv = v3(0.0f, 0.0f, 0.0f), o_lo = v3(0.0f, 0.0f, 0.0f), o_hi = v3(0.0f, 0.0f, 0.0f);
-    if (BOXES && tile.box) {
-        inv = v3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
-        const float grow = __builtin_amdgcn_sqrtf(vdot(op, op)) * (0x1p-9f * (1.0f + 0x1p-10f));
-        o_lo = v3(op.x + grow, op.y + grow, op.z + grow);           // lower planes move down by `grow`: plane - (o + grow)
-        o_hi = v3(op.x - grow, op.y - grow, op.z - grow);
-    }
     uint32_t blk = 0u;
     for (; blk + 32u <= count; blk += 32u) {                           // full blocks: one address, constant offsets
         if (BOXES && tile.box) {
@@ -1721,7 +1732,7 @@ RT_DEV void render_queue_stream_body(const Scene& sc, uint32_t* __restrict__ rgb
     float4* geo = rt_lds;
     float4* geo0 = rt_lds + S;
     float4* box = geo0 + S;                                       // the boxes of the tile's blocks (scan_tile), 2 x S / 32
-    const uint32_t box_f4 = L.scan_blocks ? 2u * (S / 32u) : 0u;
+    const uint32_t box_f4 = L.scan_blocks ? 2u * (S / 32u) + 2u : 0u;   // ... and the tile's own box behind them
     char* mine = reinterpret_cast<char*>(box + box_f4) + wave * (RT_Q_CAND_CAP * 128u + 48u * P + RT_Q_WORDS * 256u + RT_UL_BYTES(L.ulist_cap));
     Cand cand;
     cand.col = reinterpret_cast<uint16_t*>(mine) + lane;
@@ -1834,8 +1845,10 @@ RT_DEV void render_queue_stream_body(const Scene& sc, uint32_t* __restrict__ rgb
                     geo0[i] = camterms[first + i];
                 }
                 // (every wavefront stages its share of the tile and of the blocks' boxes, whichever sweep it is in)
-                for (uint32_t i = threadIdx.x; i < box_f4 && first / 16u + i < 2u * L.scan_blocks; i += blockDim.x)
-                    box[i] = sc.geom[L.n_padded + first / 16u + i];
+                for (uint32_t i = threadIdx.x; i < box_f4; i += blockDim.x) {
+                    if (i >= box_f4 - 2u) box[i] = sc.geom[L.n_padded + 2u * L.scan_blocks + 2u * (first / S) + (i - (box_f4 - 2u))];
+                    else if (first / 16u + i < 2u * L.scan_blocks) box[i] = sc.geom[L.n_padded + first / 16u + i];
+                }
                 __syncthreads();
                 const Tile tile = {geo, sc.exact + first, nullptr, sc.mat + L.n_padded};   // exact-test data from global memory
                 if (traced) {
@@ -1879,10 +1892,12 @@ RT_DEV void render_queue_stream_body(const Scene& sc, uint32_t* __restrict__ rgb
                     geo[i] = sc.geom[first + i];
                     geo0[i] = camterms[first + i];
                 }
-                for (uint32_t i = threadIdx.x; i < box_f4 && first / 16u + i < 2u * L.scan_blocks; i += blockDim.x)
-                    box[i] = sc.geom[L.n_padded + first / 16u + i];          // (2 float4 per 32 spheres)
+                for (uint32_t i = threadIdx.x; i < box_f4; i += blockDim.x) {
+                    if (i >= box_f4 - 2u) box[i] = sc.geom[L.n_padded + 2u * L.scan_blocks + 2u * (first / S) + (i - (box_f4 - 2u))];
+                    else if (first / 16u + i < 2u * L.scan_blocks) box[i] = sc.geom[L.n_padded + first / 16u + i];
+                }
                 __syncthreads();
-                const Tile tile = {geo, sc.exact + first, box_f4 ? box : nullptr, sc.mat + L.n_padded};   // exact-test data from global memory
+                const Tile tile = {geo, sc.exact + first, box_f4 ? box : nullptr, sc.mat + L.n_padded, box_f4 ? box + (box_f4 - 2u) : nullptr};   // exact-test data from global memory
                 if (active) scan_tile<true, true>(tile, count, (int)first, T, L.scan_scale, p.o, p.d, ra, L.t_min, b, cand, st);
             }
             if (active) {
