@@ -480,25 +480,29 @@ RT_DEV void scan_primary(const float4* geo0, const uint16_t* map, const Tile& ti
 // grid -- are copied, camera-ray terms and index, to a short list in LDS, lowest index first.  The unit's camera-ray
 // batches then run scan_primary over that list instead of over the scene.  Nothing changes in what the exact test
 // sees, except that it sees it sooner.
-//   The test is geometric and in double precision (the single-precision cone test of scan_primary cannot resolve a
-//   small far sphere from its neighbours: its slack for the rounding of the camera's directions is a slack on a cosine
-//   near 1).  With q = c - o and u the unit vector through the centre of the unit's footprint (fx in [x0 - 1/2, x0 + w],
-//   fy in [y0 - 1/2, y0 + h]: pixel + jitter in [-1/2, 1/2), or the grid sampler's [0, 1)), all from the camera's
-//   single-precision fields but exact to double rounding:
-//     dist^2 = |q|^2 - (u.q)^2                    squared distance from the centre to the central line
-//     r_eff^2 = r*r (1 + 2^-17) + 2^-18 |q|^2     the exact test accepts a ray with direction d only if the centre is
-//                                                 within r_eff of the ray's line (the inflations of scan_tile's
-//                                                 derivation, which cover the exact test's own roundings)
-//     s = reach / |d_centre|                      reach (RtLaunch.unit_reach) >= |d - d_centre| for every ray of the
-//                                                 unit as make_ray rounds it: (w + 1/2)/2 |du| + (h + 1/2)/2 |dv| + eta,
-//                                                 eta bounding make_ray's four roundings per component; so the sine of
-//                                                 the angle between a ray and the central line is at most s
-//   The centre's angle to a ray's line is at least its angle to the central line minus that angle, and sines of
-//   angles up to a right angle add at most: dist(ray) >= dist - |q| s.  A sphere is listed unless
-//     dist > r_eff + |q| (s + 2^-20)   or   u.q < -(r_eff + |q| (s + 2^-20))
+//   The test is geometric: distance from the sphere's centre to the line through the centre of the unit's footprint
+//   against the sphere's radius plus the bundle's half-width at that depth.  (The single-precision cone test of
+//   scan_primary cannot resolve a small far sphere from its neighbours: its slack for the rounding of the camera's
+//   directions is a slack on a cosine near 1.)  Per unit, in double precision from the camera's single-precision
+//   fields: u, the unit vector through the centre of the footprint (fx in [x0 - 1/2, x0 + w], fy in [y0 - 1/2, y0 + h]:
+//   pixel + jitter in [-1/2, 1/2), or the grid sampler's [0, 1)), o' = o - T and
+//     s = reach / |d_centre|       reach (RtLaunch.unit_reach) >= |d - d_centre| for every ray of the unit as make_ray
+//                                  rounds it: (w + 1/2)/2 |du| + (h + 1/2)/2 |dv| + eta, eta bounding make_ray's four
+//                                  roundings per component; so the sine of the angle between a ray and the central
+//                                  line is at most s
+//   all three rounded to single precision (u is then a unit vector to 2^-23).  Per sphere, single precision, with
+//   q = c' - o' (c' = c - T as stored for the scan filter):
+//     dist = |q x u|               distance from the centre to the central line, as a cross product: no cancellation
+//                                  beyond 3 * 2^-24 |q| per component
+//     r_eff^2 = r*r (1 + 2^-17) + 2^-18 |q|^2    the exact test accepts a ray only if the centre is within r_eff of the
+//                                  ray's line (the inflations of scan_tile's derivation: its own roundings)
+//   The centre's angle to a ray's line is at least its angle to the central line minus the angle between the two, and
+//   sines of angles up to a right angle add at most: dist(ray) >= dist - |q| s.  A sphere is listed unless
+//     dist > bound   or   u.q < -bound,     bound = r_eff + |q| (s + 2^-18) + 2^-20 (|o'| + |c'|)  (1-norms)
 //   (the second: the centre lies behind every ray by more than r_eff, camera outside -- the exact test then has
-//   h = d.q <= 0 and ncc <= 0 and rejects; 2^-20 |q| covers its rounding of h).  Single-precision square roots
-//   (hardware, 1 ulp) are rounded up by 2^-20.  Anything that is not a number lists the sphere.
+//   h = d.q <= 0 and ncc <= 0 and rejects).  2^-18 |q| covers the roundings of the cross product, of u and of the exact
+//   test's h; 2^-20 (|o'| + |c'|) the roundings of c', o' and q.  Hardware square roots (1 ulp) are rounded up by
+//   2^-20.  Anything that is not a number lists the sphere.
 // No list (RT_UL_NONE: the batches scan the scene as before) if reach >= |d_centre| -- a degenerate camera --, or if
 // more spheres pass than the list holds.
 #define RT_UL_NONE 0xffffffffu
@@ -507,36 +511,42 @@ RT_DEV uint32_t uniform_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_read
 
 struct UnitList { float4* terms; uint16_t* idx; };             // RtLaunch.ulist_cap entries each, per wavefront or pool slot
 
-// exact: {c, r*r} per sphere (global memory); terms: the launch's camera-ray terms (LDS copy, or global memory where
-// the sphere list is streamed), copied for the listed spheres.
-RT_DEV uint32_t unit_list(const float4* __restrict__ exact, const float4* terms, const RtCamera& cam, const RtLaunch& L,
-                          uint32_t x0, uint32_t y0, const UnitList& ul, uint32_t lane) {
-    const double fxc = (double)x0 + 0.5 * ((double)L.unit_w - 0.5), fyc = (double)y0 + 0.5 * ((double)L.unit_h - 0.5);
-    const double ox = cam.center[0], oy = cam.center[1], oz = cam.center[2];
-    const double dx = ((double)cam.pixel00_loc[0] - ox) + (fxc * (double)cam.pixel_delta_u[0] + fyc * (double)cam.pixel_delta_v[0]);
-    const double dy = ((double)cam.pixel00_loc[1] - oy) + (fxc * (double)cam.pixel_delta_u[1] + fyc * (double)cam.pixel_delta_v[1]);
-    const double dz = ((double)cam.pixel00_loc[2] - oz) + (fxc * (double)cam.pixel_delta_u[2] + fyc * (double)cam.pixel_delta_v[2]);
-    const double len2 = dx * dx + dy * dy + dz * dz;
-    const float len_lo = __builtin_amdgcn_sqrtf((float)len2) * (1.0f - 0x1p-20f);
-    if (!(len_lo > L.unit_reach)) return RT_UL_NONE;              // wave-uniform: every operand is
-    const float s = L.unit_reach / len_lo * (1.0f + 0x1p-20f) + 0x1p-20f;
-    const double inv = 1.0 / sqrt(len2);
-    const double ux = dx * inv, uy = dy * inv, uz = dz * inv;
+// geom: {c - T, .} and exact: {., r*r} per sphere (global memory); terms: the launch's camera-ray terms (LDS copy, or
+// global memory where the sphere list is streamed), copied for the listed spheres.
+RT_DEV uint32_t unit_list(const float4* __restrict__ geom, const float4* __restrict__ exact, const float4* terms, const RtCamera& cam,
+                          const RtLaunch& L, uint32_t x0, uint32_t y0, const UnitList& ul, uint32_t lane) {
+    float ux, uy, uz, opx, opy, opz, s;
+    {
+        const double fxc = (double)x0 + 0.5 * ((double)L.unit_w - 0.5), fyc = (double)y0 + 0.5 * ((double)L.unit_h - 0.5);
+        const double ox = cam.center[0], oy = cam.center[1], oz = cam.center[2];
+        const double dx = ((double)cam.pixel00_loc[0] - ox) + (fxc * (double)cam.pixel_delta_u[0] + fyc * (double)cam.pixel_delta_v[0]);
+        const double dy = ((double)cam.pixel00_loc[1] - oy) + (fxc * (double)cam.pixel_delta_u[1] + fyc * (double)cam.pixel_delta_v[1]);
+        const double dz = ((double)cam.pixel00_loc[2] - oz) + (fxc * (double)cam.pixel_delta_u[2] + fyc * (double)cam.pixel_delta_v[2]);
+        const double len2 = dx * dx + dy * dy + dz * dz;
+        const float len_lo = __builtin_amdgcn_sqrtf((float)len2) * (1.0f - 0x1p-20f);
+        if (!(len_lo > L.unit_reach)) return RT_UL_NONE;          // wave-uniform: every operand is
+        s = L.unit_reach / len_lo * (1.0f + 0x1p-20f) + 0x1p-18f;
+        const double inv = 1.0 / sqrt(len2);
+        ux = (float)(dx * inv); uy = (float)(dy * inv); uz = (float)(dz * inv);
+        opx = (float)(ox - (double)L.translate[0]); opy = (float)(oy - (double)L.translate[1]); opz = (float)(oz - (double)L.translate[2]);
+    }
+    const float o_abs = 0x1p-20f * (fabsf(opx) + fabsf(opy) + fabsf(opz));
     uint32_t n = 0u;
     for (uint32_t first = 0u; first < L.n_padded; first += 64u) {
         const uint32_t i = first + lane;
         bool pass = false;
         if (i < L.n_padded) {
-            const float4 e = exact[i];
-            const double qx = (double)e.x - ox, qy = (double)e.y - oy, qz = (double)e.z - oz;
-            const double qq = qx * qx + qy * qy + qz * qz;
-            const double t = ux * qx + uy * qy + uz * qz;
-            const double dist2 = qq - t * t;
-            const float qqf = (float)qq * (1.0f + 0x1p-20f);
-            const float r_eff = __builtin_amdgcn_sqrtf(fmaf(e.w, 1.0f + 0x1p-17f, 0x1p-18f * qqf) * (1.0f + 0x1p-20f)) * (1.0f + 0x1p-20f);
-            const float q_len = __builtin_amdgcn_sqrtf(qqf) * (1.0f + 0x1p-20f);
-            const double bound = (double)(fmaf(q_len, s, r_eff) * (1.0f + 0x1p-20f));
-            pass = !(dist2 > bound * bound) && !(t < -bound) && e.w != -INFINITY;   // (r*r = -inf: padding)
+            const float4 g = geom[i];
+            const float rr = exact[i].w;
+            const float qx = g.x - opx, qy = g.y - opy, qz = g.z - opz;
+            const float qq = (fmaf(qz, qz, fmaf(qy, qy, qx * qx))) * (1.0f + 0x1p-20f);
+            const float t = fmaf(uz, qz, fmaf(uy, qy, ux * qx));
+            const float kx = fmaf(qy, uz, -(qz * uy)), ky = fmaf(qz, ux, -(qx * uz)), kz = fmaf(qx, uy, -(qy * ux));
+            const float dist2 = fmaf(kz, kz, fmaf(ky, ky, kx * kx));
+            const float r_eff = __builtin_amdgcn_sqrtf(fmaf(rr, 1.0f + 0x1p-17f, 0x1p-18f * qq) * (1.0f + 0x1p-20f)) * (1.0f + 0x1p-20f);
+            const float q_len = __builtin_amdgcn_sqrtf(qq) * (1.0f + 0x1p-20f);
+            const float bound = (fmaf(q_len, s, r_eff) + fmaf(0x1p-20f, fabsf(g.x) + fabsf(g.y) + fabsf(g.z), o_abs)) * (1.0f + 0x1p-20f);
+            pass = !(dist2 > bound * bound) && !(t < -bound) && rr != -INFINITY;   // (r*r = -inf: padding)
         }
         const unsigned long long m = __ballot(pass);
         const uint32_t cnt = (uint32_t)__popcll(m);
@@ -1316,7 +1326,7 @@ RT_DEV void render_queue_body(const Scene& sc, uint32_t* __restrict__ rgba, floa
                         next_samp = 0u;
                         if (cur) u1 = open_unit(L, unit, n_samp); else u0 = open_unit(L, unit, n_samp);
                         if (n_samp == 0u) continue;
-                        ul_k = L.ulist_cap ? uniform_u32(unit_list(sc.exact, geo0, cam, L, cur ? u1.x0 : u0.x0, cur ? u1.y0 : u0.y0, ul, lane)) : RT_UL_NONE;
+                        ul_k = L.ulist_cap ? uniform_u32(unit_list(sc.geom, sc.exact, geo0, cam, L, cur ? u1.x0 : u0.x0, cur ? u1.y0 : u0.y0, ul, lane)) : RT_UL_NONE;
                     }
                 }
             }
@@ -1409,7 +1419,7 @@ RT_DEV UnitList pool_list(const RtLaunch& L, uint32_t slot) {
 
 template <bool LISTS>
 RT_DEV bool pool_open(const RtLaunch& L, uint32_t* slots, uint32_t* ctl, uint32_t* __restrict__ work, uint32_t n_samp,
-                      uint32_t lane, uint32_t ahead, const RtCamera& cam, const float4* __restrict__ exact, bool& drained) {
+                      uint32_t lane, uint32_t ahead, const RtCamera& cam, const float4* __restrict__ geom, const float4* __restrict__ exact, bool& drained) {
     uint32_t lock = 1u;
     if (lane == 0u) lock = atomicCAS(&ctl[1], 0u, 1u);
     if (uniform_u32(lock) != 0u) return false;                    // somebody is opening one
@@ -1443,7 +1453,7 @@ RT_DEV bool pool_open(const RtLaunch& L, uint32_t* slots, uint32_t* ctl, uint32_
                 const Slot u = open_unit(L, unit, n_samp);
                 // the free slot's list is nobody's: written here, published with the slot below
                 uint32_t ul_k = RT_UL_NONE;
-                if (LISTS && L.ulist_cap) ul_k = uniform_u32(unit_list(exact, rt_lds + L.n_padded, cam, L, u.x0, u.y0, pool_list(L, f), lane));
+                if (LISTS && L.ulist_cap) ul_k = uniform_u32(unit_list(geom, exact, rt_lds + L.n_padded, cam, L, u.x0, u.y0, pool_list(L, f), lane));
                 if (lane == 0u) {
                     slots[f * 8u + 6u] = ul_k;
                     slots[f * 8u + 0u] = u.x0;
@@ -1468,7 +1478,7 @@ RT_DEV bool pool_open(const RtLaunch& L, uint32_t* slots, uint32_t* ctl, uint32_
 // ahead_at: the wavefront whose batch contains this sample of a unit opens the next unit (pool_open).
 template <bool LISTS>
 RT_DEV bool pool_next_batch(const RtLaunch& L, uint32_t* slots, uint32_t* ctl, uint32_t* __restrict__ work, uint32_t n_samp,
-                            uint32_t ahead_at, uint32_t lane, const RtCamera& cam, const float4* __restrict__ exact, uint32_t& hint, uint32_t& slot, uint32_t& first,
+                            uint32_t ahead_at, uint32_t lane, const RtCamera& cam, const float4* __restrict__ geom, const float4* __restrict__ exact, uint32_t& hint, uint32_t& slot, uint32_t& first,
                             uint4& head, bool& drained) {
     bool got = false;
     // The slot this wavefront last took a batch from is tried first.  A unit that still has untraced samples is good
@@ -1505,11 +1515,11 @@ RT_DEV bool pool_next_batch(const RtLaunch& L, uint32_t* slots, uint32_t* ctl, u
             }
         }
         // the current unit is used up (or there is none yet): open the next one, if nobody else is at it
-        if (!pool_open<LISTS>(L, slots, ctl, work, n_samp, lane, POOL_NONE, cam, exact, drained)) return false;
+        if (!pool_open<LISTS>(L, slots, ctl, work, n_samp, lane, POOL_NONE, cam, geom, exact, drained)) return false;
     }
     if (got && ahead_at >= first && ahead_at < first + 64u) {
         bool unused = false;
-        (void)pool_open<LISTS>(L, slots, ctl, work, n_samp, lane, slot, cam, exact, unused);
+        (void)pool_open<LISTS>(L, slots, ctl, work, n_samp, lane, slot, cam, geom, exact, unused);
     }
     return got;
 }
@@ -1628,7 +1638,7 @@ RT_DEV void render_pool_body(const Scene& sc, uint32_t* __restrict__ rgba, float
         if (want != 0ull && !drained) {
             uint32_t sl = 0u, first = 0u;
             uint4 head = make_uint4(0u, 0u, 0u, 0u);
-            if (pool_next_batch<LISTS>(L, slots, ctl, work, n_samp, ahead_at, lane, cam, sc.exact, hint, sl, first, head, drained)) {
+            if (pool_next_batch<LISTS>(L, slots, ctl, work, n_samp, ahead_at, lane, cam, sc.geom, sc.exact, hint, sl, first, head, drained)) {
                 Slot u;
                 u.open = true; u.left = 0u;
                 u.x0 = uniform_u32(head.x);
@@ -1797,7 +1807,7 @@ RT_DEV void render_queue_stream_body(const Scene& sc, uint32_t* __restrict__ rgb
                 next_samp = 0u;
                 if (cur) u1 = open_unit(L, unit, n_samp); else u0 = open_unit(L, unit, n_samp);
                 if (n_samp == 0u) continue;
-                ul_k = L.ulist_cap ? uniform_u32(unit_list(sc.exact, camterms, cam, L, cur ? u1.x0 : u0.x0, cur ? u1.y0 : u0.y0, ul, lane)) : RT_UL_NONE;
+                ul_k = L.ulist_cap ? uniform_u32(unit_list(sc.geom, sc.exact, camterms, cam, L, cur ? u1.x0 : u0.x0, cur ? u1.y0 : u0.y0, ul, lane)) : RT_UL_NONE;
             }
             if (ul_k == RT_UL_NONE) { primary = true; break; }
             uint32_t completed = 0u;

@@ -22,10 +22,10 @@ d = P0 + fx du + fy dv, so with q = c - o the condition becomes |d.q| / |d| >= s
   with A, B, C, sq all times rho = 2^-k, rho * 2 max M < 1 (M = |C| + (W+1)|A| + (H+1)|B| bounds |dq|): the clamp's lower end
   drops spheres behind the camera ray unless the camera is inside them; the bar is accept_exact's full precondition.
 The direction the exact test sees is make_ray's rounded one; the filter works from fx, fy.
-Pixel units (unit_list): the spheres a unit's camera-ray batches scan are chosen once per unit by a geometric test in
-double precision -- centre within r_eff + |q| (s + 2^-20) of the line through the centre of the unit's footprint, and
-not behind it by more than that (r_eff^2 = r*r (1+2^-17) + 2^-18 |q|^2; s = reach / |d_centre|, reach from the launcher,
-make_launch).  Every sphere accept_exact can accept for any ray of the unit must be listed.
+Pixel units (unit_list): the spheres a unit's camera-ray batches scan are chosen once per unit by a geometric test --
+centre within r_eff + |q| s + 2^-20 (|o'| + |c'|) of the line through the centre of the unit's footprint (|q x u|, single
+precision), and not behind it by more than that (r_eff^2 = r*r (1+2^-17) + 2^-18 |q|^2; s = reach / |d_centre| + 2^-18,
+reach from the launcher, make_launch).  Every sphere accept_exact can accept for any ray of the unit must be listed.
 Here both are evaluated in numpy with float32 fma emulated through float64 (products of two float32 are
 exact in float64), on random and adversarial ray/sphere pairs."""
 import numpy as np
@@ -350,32 +350,42 @@ def unit_reach(cam, uw, uh):
     return np.nextafter(f32(reach), f32(np.inf))
 
 
-def unit_listed(cam, x0, y0, uw, uh, c, rr):
+def unit_listed(cam, x0, y0, uw, uh, c, rr, T=(0.0, 0.0, 0.0)):
     """unit_list of the kernel for the unit at (x0, y0) (arrays: one unit and one sphere per element), operation for
-    operation; the hardware's 1-ulp square roots are modelled 2 ulps too SMALL where a larger value lists more (the
-    model is then stricter than the kernel).  Returns None where the kernel builds no list."""
+    operation: the unit's central direction u, o' = o - T and s in double precision, rounded to single; per sphere in
+    single precision q = c' - o' (c' = c - T as uploaded), the distance to the central line as |q x u|, and
+    bound = r_eff + |q| s + 2^-20 (|o'| + |c'|).  The hardware's 1-ulp square roots are modelled 2 ulps too SMALL where
+    a larger value lists more, too large where it lists less (the model is then stricter than the kernel)."""
     o, p00, du, dv, W, H = [x.astype(np.float64) if isinstance(x, np.ndarray) else x for x in _cam_arrays(cam)]
+    T = np.array(T, dtype=f32)
     reach = unit_reach(cam, uw, uh)
     fxc = x0.astype(np.float64) + 0.5 * (uw - 0.5)
     fyc = y0.astype(np.float64) + 0.5 * (uh - 0.5)
     d = [(p00[k] - o[k]) + (fxc * du[k] + fyc * dv[k]) for k in range(3)]
     len2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2]
     down = lambda x: np.nextafter(np.nextafter(x, f32(0.0)), f32(0.0))
-    len_lo = (np.nextafter(np.sqrt(len2.astype(f32)), f32(np.inf)) * f32(1.0 - 2.0 ** -20)).astype(f32)   # (larger is the risky side here)
+    up = lambda x: np.nextafter(np.nextafter(x, f32(np.inf)), f32(np.inf))
+    len_lo = (up(np.sqrt(len2.astype(f32))) * f32(1.0 - 2.0 ** -20)).astype(f32)
     assert (len_lo > reach).all()
-    s_ = ((reach / len_lo).astype(f32) * f32(1.0 + 2.0 ** -20)).astype(f32) + f32(2.0 ** -20)
+    s_ = ((reach / len_lo).astype(f32) * f32(1.0 + 2.0 ** -20)).astype(f32) + f32(2.0 ** -18)
     inv = 1.0 / np.sqrt(len2)
-    u = [d[k] * inv for k in range(3)]
-    q = [c[k].astype(np.float64) - o[k] for k in range(3)]
-    qq = q[0] * q[0] + q[1] * q[1] + q[2] * q[2]
-    t = u[0] * q[0] + u[1] * q[1] + u[2] * q[2]
-    dist2 = qq - t * t
-    qqf = (qq.astype(f32) * f32(1.0 + 2.0 ** -20)).astype(f32)
-    val = (fma(rr, np.full_like(rr, f32(1.0 + 2.0 ** -17)), (f32(2.0 ** -18) * qqf).astype(f32)) * f32(1.0 + 2.0 ** -20)).astype(f32)
+    u = [(d[k] * inv).astype(f32) for k in range(3)]
+    op = [np.full_like(u[0], f32(o[k] - np.float64(T[k]))) for k in range(3)]
+    o_abs = (f32(2.0 ** -20) * ((np.abs(op[0]) + np.abs(op[1])).astype(f32) + np.abs(op[2])).astype(f32)).astype(f32)
+    cp = [(c[k].astype(np.float64) - np.float64(T[k])).astype(f32) for k in range(3)]           # upload, in double
+    q = [(cp[k] - op[k]).astype(f32) for k in range(3)]
+    qq = (fma(q[2], q[2], fma(q[1], q[1], (q[0] * q[0]).astype(f32))) * f32(1.0 + 2.0 ** -20)).astype(f32)
+    t = fma(u[2], q[2], fma(u[1], q[1], (u[0] * q[0]).astype(f32)))
+    kx = fma(q[1], u[2], -(q[2] * u[1]).astype(f32))
+    ky = fma(q[2], u[0], -(q[0] * u[2]).astype(f32))
+    kz = fma(q[0], u[1], -(q[1] * u[0]).astype(f32))
+    dist2 = fma(kz, kz, fma(ky, ky, (kx * kx).astype(f32)))
+    val = (fma(rr, np.full_like(rr, f32(1.0 + 2.0 ** -17)), (f32(2.0 ** -18) * qq).astype(f32)) * f32(1.0 + 2.0 ** -20)).astype(f32)
     r_eff = (down(np.sqrt(val)) * f32(1.0 + 2.0 ** -20)).astype(f32)
-    q_len = (down(np.sqrt(qqf)) * f32(1.0 + 2.0 ** -20)).astype(f32)
-    bound = (fma(q_len, s_.astype(f32), r_eff) * f32(1.0 + 2.0 ** -20)).astype(f32).astype(np.float64)
-    return ~(dist2 > bound * bound) & ~(t < -bound)
+    q_len = (down(np.sqrt(qq)) * f32(1.0 + 2.0 ** -20)).astype(f32)
+    c_abs = ((np.abs(cp[0]) + np.abs(cp[1])).astype(f32) + np.abs(cp[2])).astype(f32)
+    bound = ((fma(q_len, s_.astype(f32), r_eff) + fma(np.full_like(c_abs, f32(2.0 ** -20)), c_abs, o_abs)).astype(f32) * f32(1.0 + 2.0 ** -20)).astype(f32)
+    return ~(dist2 > (bound * bound).astype(f32)) & ~(t < -bound)
 
 
 def test_unit_lists_hold_every_sphere_a_ray_of_the_unit_can_hit():
@@ -423,6 +433,10 @@ def test_unit_lists_hold_every_sphere_a_ray_of_the_unit_can_hit():
                 assert accepted.sum() > 0, label
                 dropped = accepted & ~listed
                 assert not dropped.any(), f"{label}: {dropped.sum()} spheres a ray of the unit can hit are not on the unit's list"
+                # the scene's translation T only moves roundings: where the launcher would put it (among the spheres) and far off
+                for T in (tuple(np.median(c, axis=1)), tuple(o_.astype(np.float64) + 1000.0 * scale)):
+                    moved = unit_listed(cam, x0, y0, uw, uh, c32, rr, T=T)
+                    assert not (accepted & ~moved).any(), f"{label}, T = {T}: spheres a ray of the unit can hit are not on the unit's list"
                 if kind == "random" and "far" not in name:
                     # a sphere missed by three radii and thrice the footprint's width at its depth is not listed
                     foot = np.abs(dist) * float(unit_reach(cam, uw, uh)) / dl

@@ -3,7 +3,7 @@ rt_render_queue; pooled per workgroup: rt_render_pool) is a rule on the launch s
 walks launch sizes across the rule's threshold -- the whole frame, then rank 0's interleaved row tiles of 2, 4, 8 and 16
 ranks -- on the two frames the rule was fitted on (book scene 3840x2160 at 500 spp, depth 50; mirror hall 7680x4320 at
 256 spp, depth 100), times the render kernel under each forced scheduler and under the library's own choice (HIP events
-inside the library, best of two launches), and asserts that the choice is within 2 % (+ 0.2 ms) of the faster one, and
+inside the library, best of two launches), and asserts that the scheduler it chooses is within 2 % (+ 0.2 ms) of the faster one, and
 that the three frames are the same bit for bit.  Runs late (file name) because it is the longest GPU test (~20 s)."""
 import numpy as np
 import pytest
@@ -41,7 +41,10 @@ def test_library_picks_the_faster_scheduler_across_launch_sizes():
                 assert rays["wave"] == rays["pool"] == rays["auto"] and sums["wave"] == sums["pool"] == sums["auto"]
                 fastest = min(ms["wave"], ms["pool"])
                 report.append(f"{name} 1/{world}: wave {ms['wave']:.1f} ms, pool {ms['pool']:.1f} ms, library ({kernel['auto']}) {ms['auto']:.1f} ms")
-                if ms["auto"] > 1.02 * fastest + 0.2:
+                # the library's CHOICE is judged by that scheduler's own forced timing (a third timing of the same kernel
+                # differs from the first by up to 4 % on the small launches)
+                chosen = "pool" if kernel["auto"].startswith("rt_render_pool") else "wave"
+                if ms[chosen] > 1.02 * fastest + 0.2:
                     late.append(report[-1])
     print("\n".join(report))
     assert not late, late
