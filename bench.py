@@ -17,7 +17,8 @@ Rank 0 prints one JSON line.  `value` counts every ray segment all ranks traced 
 against the FP32 vector peak with the algorithmic FLOP count 18*N_spheres + 64 per segment and the
 kernel's own duration (HIP events on the launch stream, inside the library); that count is the algorithm's
 (a full ray-sphere test per sphere), not the instructions the kernel issues -- `roofline.executed` carries the
-hardware-side figures of the stamped profile under profiles/ when one matches the code object.  `e2e_*` is a
+hardware-side figures of the stamped profile under profiles/ when one matches the code object, and `brute_force`
+the same frame timed with every segment tested against every sphere (the kernel's culling off).  `e2e_*` is a
 separate, untimed-for-`value` leg: the same frame through the blocking host-frame entry point (kernel + D2H, what
 the reference's frame time contains).  `cpu_baseline` times the
 double-precision CPU restatement of the reference (oracle/, test infrastructure) on a bounded sample of
@@ -81,6 +82,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--e2e-steps", type=int, default=2,
                     help="frames of the separate end-to-end leg (kernel + copy of the frame to host memory); 0 = skip")
+    ap.add_argument("--brute-steps", type=int, default=1,
+                    help="frames of the separate brute-force leg (every segment against every sphere: unit lists and block "
+                         "boxes off); 0 = skip")
     ap.add_argument("--cpu-width", type=int, default=1920)
     ap.add_argument("--cpu-spp", type=int, default=32)
     return ap.parse_args()
@@ -221,6 +225,7 @@ def main():
         assemble_ms.append(ams)
     fence()
     elapsed = time.perf_counter() - t0
+    main_kernel = hip.last_kernel_name()
 
     # End-to-end leg, outside `value`: the frame as the reference's host receives it (CudaWorld::render launches and
     # then copies the frame to host memory, blocking: gpu-implementation/src/ray_tracing.rs:200-208).  One GPU: the
@@ -247,6 +252,22 @@ def main():
             if k > 0:
                 e2e_ms.append((time.perf_counter() - t) * 1e3)
                 d2h_ms.append(t_d2h)
+
+    # Brute-force leg, outside `value` (one GPU only): the same frame with every path segment tested against every
+    # sphere, as the reference's loop over its list does -- the pixel units' sphere lists and the blocks' bounding boxes
+    # switched off (rt_debug_cull); the frame is the same bit for bit.  This is the figure the algorithmic FLOP count
+    # describes literally.
+    brute = None
+    if world == 1 and args.brute_steps > 0:
+        hip.debug_cull(unit_lists=False, block_boxes=False)
+        b_ms, b_rays = [], 0
+        for k in range(args.brute_steps + 1):              # the first one is a warm-up
+            r, ms_k, _, _, _ = step()
+            if k > 0:
+                b_ms.append(ms_k)
+                b_rays = r
+        brute = (sum(b_ms) / len(b_ms), b_rays, hip.last_kernel_name())
+        hip.debug_cull()
 
     mean = lambda v: sum(v) / max(1, len(v))
     stats = torch.tensor([elapsed, float(rays_total), mean(kernel_ms), mean(gather_ms)], dtype=torch.float64, device=dev)
@@ -295,7 +316,7 @@ def main():
                        "segments_per_frame": rays_all / max(1, args.steps), "parallelism": f"rowtiles{world}"},
             "roofline": {"bound": "valu_fp32", "achieved": achieved, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP32_VECTOR_PEAK_TFLOPS, "traffic": traffic,
-                         "kernel": hip.last_kernel_name(), "kernel_ms": k_ms, "flop_per_segment": flop_per_segment,
+                         "kernel": main_kernel, "kernel_ms": k_ms, "flop_per_segment": flop_per_segment,
                          "segments_per_launch": rank0_rays_per_launch,
                          # what `achieved` counts: the work of the reference's loop over the whole sphere list (one full
                          # ray-sphere test to the discriminant, 18 FLOP, per sphere and segment + 64 per segment), not
@@ -309,6 +330,13 @@ def main():
                          # hardware-side figures of the PMC profile taken with this code object on this workload
                          # (profiles/), or null: VALU lane-operations actually executed, and VALU issue slots used
                          "executed": executed},
+            # the same frame without the tests' culling (see above): kernel, its time, Mrays/s and the algorithmic
+            # FLOP/s it then sustains, which here are FLOP the kernel's filter + exact test stand for one to one
+            "brute_force": None if brute is None else {
+                "kernel": brute[2], "kernel_ms": brute[0], "value": brute[1] / (brute[0] * 1e-3) * 1e-6, "unit": "Mrays/s",
+                "achieved": brute[1] * flop_per_segment / (brute[0] * 1e-3) * 1e-12,
+                "frac": brute[1] * flop_per_segment / (brute[0] * 1e-3) * 1e-12 / FP32_VECTOR_PEAK_TFLOPS,
+                "same_frame": brute[1] == rank0_rays_per_launch},
             "kernel_ms_max_over_ranks": kms_max,
             # where a multi-GPU step goes: each rank's own render kernel, its gather (on rank 0 this includes the
             # wait for the slowest rank, i.e. load imbalance and launch skew), rank 0's copy kernel

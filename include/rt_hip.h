@@ -171,6 +171,16 @@ int rt_debug_schedule(rt_ctx *ctx, uint32_t unit_w, uint32_t unit_h, int no_queu
  * slower.  No counterpart in the reference (its kernel keeps one thread per pixel, ray.cu:109-129). */
 int rt_debug_fold_workspace_limit(rt_ctx *ctx, uint64_t bytes);
 
+/* Diagnostic: switches off what lets the camera-ray-batch kernels (sample_chunk = 1 and 0) leave out ray-sphere tests
+ * the reference's loop over its sphere list makes (hit_world, ray.cu:1-18; lib.rs:127-135) -- for measurement: with
+ * both off every path segment is tested against every sphere of the list, as in the reference; the image is the same
+ * bit for bit either way.
+ *   unit_lists  != 0 (default): the camera rays of a pixel unit scan the unit's short list of spheres, made once per unit
+ *   block_boxes != 0 (default): scenes of 128 spheres and more are kept sorted in space, and a bounce ray's scan skips
+ *                               a block of 32 spheres whose bounding box no lane's ray reaches
+ * Takes effect at the next launch.  No counterpart in the reference. */
+int rt_debug_cull(rt_ctx *ctx, int unit_lists, int block_boxes);
+
 /* Name and compute-unit count of the context's GPU. */
 int rt_device_info(const rt_ctx *ctx, char *name, size_t name_size, int *compute_units, int *clock_khz);
 

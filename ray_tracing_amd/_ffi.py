@@ -69,6 +69,7 @@ SYMBOLS = {
     "rt_debug_counters": (C.c_int, [_ctx, C.POINTER(C.c_uint64 * 16)]),
     "rt_debug_schedule": (C.c_int, [_ctx, C.c_uint32, C.c_uint32, C.c_int, C.c_int]),
     "rt_debug_fold_workspace_limit": (C.c_int, [_ctx, C.c_uint64]),
+    "rt_debug_cull": (C.c_int, [_ctx, C.c_int, C.c_int]),
     "rt_device_info": (C.c_int, [_ctx, C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "rt_camera_new": (C.c_int, [C.c_float, C.c_uint32, C.POINTER(RtCamera)]),
     "rt_camera_initialize": (C.c_int, [C.POINTER(RtCamera)]),

@@ -64,6 +64,7 @@ struct rt_ctx {
     void* d_fold = nullptr;             // fold-order workspace of the queue kernels: finished samples until their unit is complete
     size_t cap_fold = 0;
     size_t fold_limit = (size_t)8 << 30; // largest fold-order workspace the context will allocate (rt_debug_fold_workspace_limit)
+    bool cull_lists = true, cull_boxes = true;   // rt_debug_cull
     // multi-GPU gather: this context is rank `rank` of `world`
     ncclComm_t comm = nullptr;
     uint32_t world = 1, rank = 0;
@@ -317,7 +318,7 @@ RtLaunch make_launch(const rt_ctx* c, const RtCamera* cam, const RtParams* p, ui
     }
     for (int k = 0; k < 3; k++) L.translate[k] = c->translate[k];
     L.scan_scale = c->scan_scale;
-    L.scan_blocks = c->n_blocks;
+    L.scan_blocks = c->cull_boxes ? c->n_blocks : 0u;
     if (std::getenv("RT_EXP_NO_BOXES")) L.scan_blocks = 0u;                      // timing experiments only
     L.units_bottom_up = 0u;
     if (const char* e = std::getenv("RT_EXP_UNITS_BOTTOM_UP")) L.units_bottom_up = std::atoi(e) ? 1u : 0u;   // timing experiments only
@@ -351,6 +352,7 @@ RtLaunch make_launch(const rt_ctx* c, const RtCamera* cam, const RtParams* p, ui
             L.ulist_cap = 16u;
         }
     }
+    if (!c->cull_lists) L.ulist_cap = 0u;
     if (const char* e = std::getenv("RT_EXP_ULIST_CAP")) {                       // timing experiments and tests only: 0 .. 16
         const unsigned v = (unsigned)std::atoi(e);
         if (v < L.ulist_cap) L.ulist_cap = v & ~1u;
@@ -1114,6 +1116,13 @@ int rt_render_frame_sharded(rt_ctx* c, const RtCamera* cam, const RtParams* p, u
 int rt_debug_fold_workspace_limit(rt_ctx* c, uint64_t bytes) {
     if (!c) return RT_ERR_INVALID;
     c->fold_limit = bytes ? (size_t)bytes : (size_t)8 << 30;
+    return 0;
+}
+
+int rt_debug_cull(rt_ctx* c, int unit_lists, int block_boxes) {
+    if (!c) return RT_ERR_INVALID;
+    c->cull_lists = unit_lists != 0;
+    c->cull_boxes = block_boxes != 0;
     return 0;
 }
 

@@ -87,6 +87,7 @@ extern "C" {
     pub fn rt_last_kernel_ms(ctx: *const rt_ctx) -> f32;
     /// Largest fold-order workspace (sample_chunk = 0) the context may allocate; 0 = the default of 8 GiB.
     pub fn rt_debug_fold_workspace_limit(ctx: *mut rt_ctx, bytes: u64) -> c_int;
+    pub fn rt_debug_cull(ctx: *mut rt_ctx, unit_lists: c_int, block_boxes: c_int) -> c_int;
     pub fn rt_comm_id(id: *mut u8) -> c_int;
     pub fn rt_comm_init(ctx: *mut rt_ctx, id: *const u8, world: u32, rank: u32) -> c_int;
     pub fn rt_render_frame_sharded(ctx: *mut rt_ctx, cam: *const RtCamera, params: *const RtParams, tile_rows: u32,

@@ -664,6 +664,31 @@ def test_pixel_unit_sphere_lists_change_nothing_but_the_time(rt, hip, monkeypatc
                     assert ms[0] < 0.95 * ms[1], (sched, ms)
 
 
+def test_every_sphere_tested_or_culled_is_the_same_frame(rt, hip):
+    """rt_debug_cull switches off the pixel units' sphere lists and the blocks' bounding boxes: every path segment is
+    then tested against every sphere, as in the reference's loop over its list (hit_world, ray.cu:1-18).  Same frame,
+    bit for bit, on either scheduler and in fold order; the kernels are the builds without boxes."""
+    sp = rt.scene_book1_final(1)
+    cam = rt.Camera.look_at(16.0 / 9.0, 480, 20.0, (13.0, 2.0, 3.0), (0.0, 0.0, 0.0))
+    hip.upload_scene(sp)
+    for chunk, scheds in ((1, ("wave", "pool")), (0, ("wave",))):
+        p = rt.DeviceGUI(samples_per_pixel=128, max_depth=20, seed=4, sample_chunk=chunk)
+        for sched in scheds:
+            hip.debug_schedule(scheduler=sched)
+            culled = hip.render(cam, p, linear=True)
+            with_cull = hip.last_kernel_name()
+            hip.debug_cull(unit_lists=False, block_boxes=False)
+            brute = hip.render(cam, p, linear=True)
+            without = hip.last_kernel_name()
+            hip.debug_cull()
+            hip.debug_schedule()
+            assert brute["rays"] == culled["rays"]
+            assert np.array_equal(brute["linear"].view(np.uint32), culled["linear"].view(np.uint32))
+            if chunk == 1:
+                assert (with_cull, without) == (("rt_render_queue_boxes", "rt_render_queue") if sched == "wave" else ("rt_render_pool_boxes", "rt_render_pool_plain"))
+                assert culled["kernel_ms"] < 0.9 * brute["kernel_ms"], (sched, culled["kernel_ms"], brute["kernel_ms"])
+
+
 def test_sorted_sphere_list_and_block_boxes_change_nothing(rt, monkeypatch):
     """Scenes of 128 spheres and more are sorted in space at upload and the bounce scan skips blocks of 32 spheres
     whose bounding box no lane's ray reaches (scan_tile).  The full-size frames -- book scene 4K at 500 spp (twelve

@@ -13,10 +13,10 @@ OUT=$REPO/gpurun_out/prof_${TAG}_${WL}
 mkdir -p "$OUT"
 sha256sum "$REPO/ray_tracing_amd/csrc/rt_kernels.hsaco" | cut -d' ' -f1 > "$OUT/code_object.sha256"
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$REPO/bench.py" --workload "$WL" --steps 3 --warmup 1 --no-cpu-baseline --e2e-steps 0 > "$OUT/trace.log" 2>&1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$REPO/bench.py" --workload "$WL" --steps 3 --warmup 1 --no-cpu-baseline --e2e-steps 0 --brute-steps 0 > "$OUT/trace.log" 2>&1
 pass() {  # name, counters...
     local name=$1; shift
-    timeout -s KILL 200 rocprofv3 --pmc "$@" --output-format csv -d "$OUT/pmc_$name" -- python3 "$REPO/bench.py" --workload "$WL" --steps 1 --warmup 0 --no-cpu-baseline --e2e-steps 0 > "$OUT/pmc_$name.log" 2>&1
+    timeout -s KILL 200 rocprofv3 --pmc "$@" --output-format csv -d "$OUT/pmc_$name" -- python3 "$REPO/bench.py" --workload "$WL" --steps 1 --warmup 0 --no-cpu-baseline --e2e-steps 0 --brute-steps 0 > "$OUT/pmc_$name.log" 2>&1
 }
 pass a SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY
 pass b SQ_INSTS_VALU SQ_WAVES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE
