@@ -68,8 +68,9 @@ typedef struct RtLaunch {
 #define RT_CAND_CAP 16u
 #endif
 // Kernel for sample_chunk = 1 (camera rays in batches): candidate slots per lane, 32-bit words per queued ray
-// spheres per LDS tile when that kernel streams a longer list (more workgroups per CU than with a full tile:
-// measured on the 16,385-sphere scene, 512: 1,265 ms, 1024: 1,341 ms, 2048: 1,748 ms)
+// spheres per LDS tile when that kernel streams a longer list (a multiple of 32: a tile is whole blocks).  Measured on
+// the 16,385-sphere scene with a box per tile and per block: 256: 226 ms, 512: 207 ms, 896: 205 ms (fewer barriers
+// against larger boxes); without boxes, when every tile was scanned: 512: 1,265 ms, 1024: 1,341 ms, 2048: 1,748 ms.
 #ifndef RT_Q_STREAM_TILE
 #define RT_Q_STREAM_TILE 512u
 #endif

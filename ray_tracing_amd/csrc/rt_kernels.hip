@@ -1720,11 +1720,12 @@ RT_DEV void render_pool_body(const Scene& sc, uint32_t* __restrict__ rgba, float
     }
 }
 
-// The same for sphere lists beyond one LDS tile.  The workgroup streams the tiles in lock step, as
-// render_body<true> does; in every round each wavefront either traces its next 64 camera rays (scan_primary on
-// the tile's geo0 copy) or one segment of its bounce rays (scan_tile), whichever keeps its lanes busy: camera
-// rays when a lane is out of work and the queue is empty, bounce rays otherwise.
-//   LDS: [geo S float4][geo0 S float4], S = RT_Q_STREAM_TILE, then per wavefront as in render_queue_body.
+// The same for sphere lists beyond one LDS tile.  The workgroup streams the tiles of filter data in lock step, as
+// render_body<true> does, one segment of its lanes' bounce rays per round (scan_tile, with a box around every tile and
+// around every block of 32 spheres: most of the list is out of every lane's reach).  Camera rays need no tiles: a
+// wavefront traces its unit's next 64 between the rounds, against the unit's sphere list (unit_list) -- or, for a unit
+// with more spheres in reach than the list holds, against the launch's camera-ray terms in global memory.
+//   LDS: [geo S float4][boxes 2 x S / 32 + 2 float4], S = RT_Q_STREAM_TILE, then per wavefront as in render_queue_body.
 template <bool FOLD>
 RT_DEV void render_queue_stream_body(const Scene& sc, uint32_t* __restrict__ rgba, float4* __restrict__ linear,
                                      unsigned long long* __restrict__ segments, uint32_t* __restrict__ work,
@@ -1740,8 +1741,7 @@ RT_DEV void render_queue_stream_body(const Scene& sc, uint32_t* __restrict__ rgb
     const V3 T = ld3(L.translate);
 
     float4* geo = rt_lds;
-    float4* geo0 = rt_lds + S;
-    float4* box = geo0 + S;                                       // the boxes of the tile's blocks (scan_tile), 2 x S / 32
+    float4* box = geo + S;                                        // the boxes of the tile's blocks (scan_tile), 2 x S / 32
     const uint32_t box_f4 = L.scan_blocks ? 2u * (S / 32u) + 2u : 0u;   // ... and the tile's own box behind them
     char* mine = reinterpret_cast<char*>(box + box_f4) + wave * (RT_Q_CAND_CAP * 128u + 48u * P + RT_Q_WORDS * 256u + RT_UL_BYTES(L.ulist_cap));
     Cand cand;
@@ -1751,7 +1751,8 @@ RT_DEV void render_queue_stream_body(const Scene& sc, uint32_t* __restrict__ rgb
     unsigned long long* accum = reinterpret_cast<unsigned long long*>(mine + RT_Q_CAND_CAP * 128u);
     uint32_t* q = reinterpret_cast<uint32_t*>(mine + RT_Q_CAND_CAP * 128u + 48u * P);
     // the list of the unit whose camera rays are being traced (unit_list, from the camera-ray terms in global memory):
-    // with it a camera-ray batch needs no sweep over the tiles and is traced between the workgroup's rounds
+    // a camera-ray batch needs no sweep over the tiles and is traced between the workgroup's rounds.  A unit without a
+    // list (more spheres in reach than the list holds) scans the launch's camera-ray terms in global memory instead.
     UnitList ul;
     ul.terms = reinterpret_cast<float4*>(mine + RT_Q_CAND_CAP * 128u + 48u * P + RT_Q_WORDS * 256u);
     ul.idx = reinterpret_cast<uint16_t*>(ul.terms + L.ulist_cap);
@@ -1777,9 +1778,7 @@ RT_DEV void render_queue_stream_body(const Scene& sc, uint32_t* __restrict__ rgb
 
     for (;;) {
         // Between the workgroup's rounds: lanes without a path take queued rays; while some are still without one and
-        // the queue is empty, the next camera rays of a unit WITH a list are traced on the spot (no tiles needed).  A
-        // unit without a list has its camera rays traced in a round of their own (primary).
-        bool primary = false;
+        // the queue is empty, the unit's next camera rays are traced on the spot (no tiles needed).
         unsigned long long want;
         for (;;) {
             if (u0.open && u0.left == 0u) { write_unit(L, u0, accum, lane, true, rgba, linear, fold); u0.open = false; }
@@ -1809,9 +1808,8 @@ RT_DEV void render_queue_stream_body(const Scene& sc, uint32_t* __restrict__ rgb
                 if (n_samp == 0u) continue;
                 ul_k = L.ulist_cap ? uniform_u32(unit_list(sc.geom, sc.exact, camterms, cam, L, cur ? u1.x0 : u0.x0, cur ? u1.y0 : u0.y0, ul, lane)) : RT_UL_NONE;
             }
-            if (ul_k == RT_UL_NONE) { primary = true; break; }
             uint32_t completed = 0u;
-            primary_batch<true>(sc, whole, geo0, cam, L, seed, T, cur ? u1 : u0, cur, next_samp, n_samp, accum, fold, q, cand, ul, ul_k,
+            primary_batch<true>(sc, whole, camterms, cam, L, seed, T, cur ? u1 : u0, cur, next_samp, n_samp, accum, fold, q, cand, ul, ul_k,
                                 q_count, completed, nseg, st);
             q_head = 0u;
             next_samp = next_samp + 64u < n_samp ? next_samp + 64u : n_samp;
@@ -1820,105 +1818,33 @@ RT_DEV void render_queue_stream_body(const Scene& sc, uint32_t* __restrict__ rgb
         const bool more = active || q_head < q_count || !drained || next_samp < n_samp || u0.open || u1.open;
         if (!__syncthreads_or(more ? 1 : 0)) break;
 
-        // This round: the wavefront's next 64 camera rays, or one segment of its lanes' bounce rays.  The two are
-        // separate sweeps over the tiles (the choice is wave-uniform), so that a camera sweep keeps only what it needs
-        // beside the lanes' held bounce paths: the camera centre is the same for every lane, and a lane's pixel, sample
-        // number and column band are recomputed after the sweep.
-        const Slot& u = cur ? u1 : u0;
+        // The round: one segment of the lanes' bounce rays, the tiles streamed through LDS in lock step.
         Best b;
         b.t = L.t_max;
         b.idx = -1;
         bool finished = false;                                   // a bounce path of this lane ended in this round
-        if (primary) {
-            const uint32_t sidx = next_samp + lane;
-            bool traced;
-            V3 bd = v3(0.0f, 0.0f, 0.0f);
-            float bfx = 0.0f, bfy = 0.0f;                        // image coordinates of the camera ray
-            {
-                const uint32_t bpix = sidx & (P - 1u), bs = sidx >> L.unit_pshift;
-                const uint32_t dx = bpix & (L.unit_w - 1u), dy = bpix >> L.unit_shift;
-                const uint32_t x = u.x0 + dx, ly = u.ly0 + dy, y = u.y0 + dy;
-                traced = sidx < n_samp && x < L.width && ly < L.rows_local && y < L.height;
-                if (traced) {
-                    V3 o_unused;
-                    sample_ray(cam, L, seed, x, y, y * L.width + x, bs, o_unused, bd, bfx, bfy);
-                }
+        const float ra = vdot(p.d, p.d);
+        for (uint32_t first = 0u; first < L.n_padded; first += RT_Q_STREAM_TILE) {
+            uint32_t count = L.n_padded - first;
+            if (count > RT_Q_STREAM_TILE) count = RT_Q_STREAM_TILE;
+            if (first) __syncthreads();                          // previous tile fully scanned
+            for (uint32_t i = threadIdx.x; i < count; i += blockDim.x) geo[i] = sc.geom[first + i];
+            for (uint32_t i = threadIdx.x; i < box_f4; i += blockDim.x) {   // (2 float4 per 32 spheres, then the tile's own two)
+                if (i >= box_f4 - 2u) box[i] = sc.geom[L.n_padded + 2u * L.scan_blocks + 2u * (first / S) + (i - (box_f4 - 2u))];
+                else if (first / 16u + i < 2u * L.scan_blocks) box[i] = sc.geom[L.n_padded + first / 16u + i];
             }
-            const V3 co = ld3(cam.center);                       // make_ray's origin
-            const float ba = vdot(bd, bd);
-            for (uint32_t first = 0u; first < L.n_padded; first += RT_Q_STREAM_TILE) {
-                uint32_t count = L.n_padded - first;
-                if (count > RT_Q_STREAM_TILE) count = RT_Q_STREAM_TILE;
-                if (first) __syncthreads();                      // previous tile fully scanned
-                for (uint32_t i = threadIdx.x; i < count; i += blockDim.x) {
-                    geo[i] = sc.geom[first + i];
-                    geo0[i] = camterms[first + i];
-                }
-                // (every wavefront stages its share of the tile and of the blocks' boxes, whichever sweep it is in)
-                for (uint32_t i = threadIdx.x; i < box_f4; i += blockDim.x) {
-                    if (i >= box_f4 - 2u) box[i] = sc.geom[L.n_padded + 2u * L.scan_blocks + 2u * (first / S) + (i - (box_f4 - 2u))];
-                    else if (first / 16u + i < 2u * L.scan_blocks) box[i] = sc.geom[L.n_padded + first / 16u + i];
-                }
-                __syncthreads();
-                const Tile tile = {geo, sc.exact + first, nullptr, sc.mat + L.n_padded};   // exact-test data from global memory
-                if (traced) {
-                    scan_primary(geo0, nullptr, tile, count, (int)first, bfx, bfy, co, bd, ba, L.t_min, b, cand, st);
-#ifdef RT_EXP_PRIMARY2
-                    scan_primary(geo0, nullptr, tile, count, (int)first, bfx, bfy, co, bd, ba, L.t_min, b, cand, st);   // cost experiment
-#endif
-                }
-            }
-            const uint32_t bpix = sidx & (P - 1u), bs = sidx >> L.unit_pshift;
-            bool cont = false, bdone = sidx < n_samp && !traced;
-            uint32_t sphere = 0u;
-            Path bp;
-            bp.o = co; bp.d = bd; bp.thr = v3(1.0f, 1.0f, 1.0f); bp.seg = 0u; bp.nb = 0u;
-            if (traced) {
-                const uint32_t dx = bpix & (L.unit_w - 1u), dy = bpix >> L.unit_shift;
-                const uint32_t x = u.x0 + dx, y = u.y0 + dy;
-                const float bband = (flags & RT_FLAG_BAND_ALBEDO) ? band_of(L, x) : 0.0f;
-                nseg++;
-                sphere = (uint32_t)b.idx;
-                V3 color;
-                if (shade_segment(sc, L, seed, b, y * L.width + x, bs, bband, bp, color, st)) {
-                    add_sample(accum, P, 3u * bpix + (cur ? 3u * P : 0u), bs, L.samples_per_pixel, color, fold);
-                    bdone = true;
-                } else {
-                    cont = true;
-                }
-            }
-            q_head = 0u;
-            q_count = queue_rays(q, cont, bp, bs, cur, bpix, sphere);
-            const uint32_t completed = (uint32_t)__popcll(__ballot(bdone));
-            if (cur) u1.left -= completed; else u0.left -= completed;
-            next_samp = next_samp + 64u < n_samp ? next_samp + 64u : n_samp;
-        } else {
-            const float ra = vdot(p.d, p.d);
-            for (uint32_t first = 0u; first < L.n_padded; first += RT_Q_STREAM_TILE) {
-                uint32_t count = L.n_padded - first;
-                if (count > RT_Q_STREAM_TILE) count = RT_Q_STREAM_TILE;
-                if (first) __syncthreads();                      // previous tile fully scanned
-                for (uint32_t i = threadIdx.x; i < count; i += blockDim.x) {
-                    geo[i] = sc.geom[first + i];
-                    geo0[i] = camterms[first + i];
-                }
-                for (uint32_t i = threadIdx.x; i < box_f4; i += blockDim.x) {
-                    if (i >= box_f4 - 2u) box[i] = sc.geom[L.n_padded + 2u * L.scan_blocks + 2u * (first / S) + (i - (box_f4 - 2u))];
-                    else if (first / 16u + i < 2u * L.scan_blocks) box[i] = sc.geom[L.n_padded + first / 16u + i];
-                }
-                __syncthreads();
-                const Tile tile = {geo, sc.exact + first, box_f4 ? box : nullptr, sc.mat + L.n_padded, box_f4 ? box + (box_f4 - 2u) : nullptr};   // exact-test data from global memory
-                if (active) scan_tile<true, true>(tile, count, (int)first, T, L.scan_scale, p.o, p.d, ra, L.t_min, b, cand, st);
-            }
-            if (active) {
-                nseg++;
-                V3 color;
-                if (shade_segment(sc, L, seed, b, pixel, s, band, p, color, st)) {
-                    add_sample(accum, P, pixslot, s, L.samples_per_pixel, color, fold);
-                    active = false;
-                    need = true;
-                    finished = true;
-                }
+            __syncthreads();
+            const Tile tile = {geo, sc.exact + first, box_f4 ? box : nullptr, sc.mat + L.n_padded, box_f4 ? box + (box_f4 - 2u) : nullptr};   // exact-test data from global memory
+            if (active) scan_tile<true, true>(tile, count, (int)first, T, L.scan_scale, p.o, p.d, ra, L.t_min, b, cand, st);
+        }
+        if (active) {
+            nseg++;
+            V3 color;
+            if (shade_segment(sc, L, seed, b, pixel, s, band, p, color, st)) {
+                add_sample(accum, P, pixslot, s, L.samples_per_pixel, color, fold);
+                active = false;
+                need = true;
+                finished = true;
             }
         }
         const unsigned long long fin = __ballot(finished);
