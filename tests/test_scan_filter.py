@@ -26,6 +26,8 @@ Pixel units (unit_list): the spheres a unit's camera-ray batches scan are chosen
 centre within r_eff + |q| s + 2^-20 (|o'| + |c'|) of the line through the centre of the unit's footprint (|q x u|, single
 precision), and not behind it by more than that (r_eff^2 = r*r (1+2^-17) + 2^-18 |q|^2; s = reach / |d_centre| + 2^-18,
 reach from the launcher, make_launch).  Every sphere accept_exact can accept for any ray of the unit must be listed.
+Block boxes (rt_upload_scene, scan_tile): a bounce ray's scan skips a block of 32 spheres unless its half-line reaches the
+block's box, grown for the ray; every sphere accept_exact can accept must lie in a block whose box the ray reaches.
 Here both are evaluated in numpy with float32 fma emulated through float64 (products of two float32 are
 exact in float64), on random and adversarial ray/sphere pairs."""
 import numpy as np
@@ -443,6 +445,106 @@ def test_unit_lists_hold_every_sphere_a_ray_of_the_unit_can_hit():
                     clear = (miss > 1.4) & (dist > 0) & (0.4 * r > 3.0 * foot) & (r > 2.0 ** -7 * np.abs(dist))   # (r_eff adds 2^-9 |q| in quadrature)
                     if clear.sum() > 100:
                         assert listed[clear].mean() < 0.01, (label, listed[clear].mean())
+
+
+# ---------------------------------------------------------------- block boxes (rt_upload_scene, scan_tile)
+def block_box(cp, r, R):
+    """rt_upload_scene: the box of a block of spheres (arrays [members, blocks]) in coordinates relative to T: every
+    sphere's own |r| (1 + 2^-10) + 2^-9 |c'| + 2^-20 R beyond its centre, rounded outwards."""
+    cc = sum(cp[k].astype(np.float64) ** 2 for k in range(3))
+    ext = np.abs(r.astype(np.float64)) * (1.0 + 2.0 ** -10) + 2.0 ** -9 * np.sqrt(cc) + 2.0 ** -20 * R
+    lo = [np.nextafter((cp[k].astype(np.float64) - ext).astype(f32), f32(-np.inf)).min(axis=0) for k in range(3)]
+    hi = [np.nextafter((cp[k].astype(np.float64) + ext).astype(f32), f32(np.inf)).max(axis=0) for k in range(3)]
+    return lo, hi
+
+
+def box_reached(lo, hi, op, d, rcp_ulp=0):
+    """scan_tile's slab test, operation for operation: the box grown by 2^-9 |o'| (1 + 2^-10) for this ray, a plane's
+    parameter (plane - o') * rcp(d), minNum / maxNum, the half-line t >= 0; reached unless tf < tn.  The hardware's
+    reciprocal is within 1 ulp (rcp_ulp moves it), its square root is modelled 2 ulps too small (a smaller box)."""
+    down = lambda x: np.nextafter(np.nextafter(x, f32(0.0)), f32(0.0))
+    with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+        inv = [(f32(1.0) / d[k]).astype(f32) for k in range(3)]
+        if rcp_ulp:
+            inv = [np.nextafter(x, np.where(x > 0, f32(np.inf), f32(-np.inf)).astype(f32) if rcp_ulp > 0 else f32(0.0)) for x in inv]
+        grow = (down(np.sqrt(dot(op, op))) * f32(2.0 ** -9 * (1.0 + 2.0 ** -10))).astype(f32)
+        a = [((lo[k] - (op[k] + grow).astype(f32)).astype(f32) * inv[k]).astype(f32) for k in range(3)]
+        b = [((hi[k] - (op[k] - grow).astype(f32)).astype(f32) * inv[k]).astype(f32) for k in range(3)]
+        tn = np.fmax(np.fmax(np.fmin(a[0], b[0]), np.fmin(a[1], b[1])), np.fmax(np.fmin(a[2], b[2]), f32(0.0)))
+        tf = np.fmin(np.fmin(np.fmax(a[0], b[0]), np.fmax(a[1], b[1])), np.fmax(a[2], b[2]))
+        return ~(tf < tn)
+
+
+def test_block_boxes_are_reached_by_every_ray_that_can_hit_a_sphere_of_the_block():
+    """Blocks of 32 spheres (clusters as the launcher's sort makes them, a flat layer resting on a ground sphere, one
+    huge member among small ones, scenes far from the translation T), bounce rays from origins on and inside spheres of
+    the scene, aimed to graze a member within a few ulps, to hit it squarely or to miss -- among them directions with
+    components that are exactly zero, denormal or 1e-30 (a degenerate diffuse bounce: the case a product-minus-product
+    slab parameter gets wrong) and origins exactly on a face of the box.  Whatever accept_exact can accept lies in a
+    block whose box the ray's half-line reaches; and the boxes are worth having: most rays that miss a block's members
+    by a few block diameters do not reach its box."""
+    rng = np.random.default_rng(10)
+    n, m = 120_000, 32
+    for label, extent, layer, far in (("clusters", 12.0, False, 0.0), ("flat layer", 12.0, True, 0.0), ("far from T", 12.0, False, 3000.0),
+                                      ("tiny scene", 0.02, False, 0.0)):
+        centre = rng.uniform(-extent, extent, (3, 1, n))
+        size = extent * rng.uniform(0.02, 0.3, (1, 1, n))
+        c = centre + rng.uniform(-1.0, 1.0, (3, m, n)) * size
+        r = size[0] * np.exp(rng.uniform(np.log(0.02), np.log(0.5), (m, n)))
+        if layer:
+            c[1] = r                                                           # resting on the plane y = 0
+            c[1, 0] = -1000.0 * extent; r[0] = 1000.0 * extent                 # ... which is a huge sphere, member 0 of every block
+            c[0, 0] = 0.0; c[2, 0] = 0.0
+        c = c + far
+        T = np.array([far, far, far]) + rng.uniform(-0.3, 0.3, 3) * extent
+        cp = [(c[k] - T[k]).astype(f32) for k in range(3)]                     # upload: c - T in double, rounded
+        c32 = [c[k].astype(f32) for k in range(3)]
+        R = float((np.sqrt(sum(cp[k].astype(np.float64) ** 2 for k in range(3))) + r).max())
+        lo, hi = block_box(cp, r.astype(f32), R)
+        # one target member per ray; origin on (or in) another sphere of the scene, a few block sizes away or right next to it
+        j = rng.integers(0, m, n)
+        idx = (j, np.arange(n))
+        tc = np.stack([c32[k][idx].astype(np.float64) for k in range(3)])
+        tr = r.astype(f32)[idx].astype(np.float64)
+        dist = size[0, 0] * np.exp(rng.uniform(np.log(0.05), np.log(60.0), n))
+        o = tc + unit(rng, n) * (tr + dist)
+        inside = rng.random(n) < 0.1
+        o = np.where(inside, tc + unit(rng, n) * tr * rng.uniform(0.0, 1.0, n), o)
+        o32 = [o[k].astype(f32) for k in range(3)]
+        for kind, miss in (("grazing", 1.0 + rng.uniform(-4e-7, 4e-7, n)), ("random", rng.uniform(0.0, 3.0, n))):
+            oc = tc - np.stack([x.astype(np.float64) for x in o32])
+            dl = np.linalg.norm(oc, axis=0)
+            w = oc / np.maximum(dl, 1e-300)
+            t = np.cross(w.T, unit(rng, n).T).T
+            t /= np.maximum(np.linalg.norm(t, axis=0), 1e-300)
+            sin_a = np.minimum((tr / np.maximum(dl, tr)) * miss, 1.0)
+            d = (w * np.sqrt(np.maximum(0.0, 1.0 - sin_a ** 2)) + t * sin_a) * rng.uniform(0.2, 3.0, n)
+            d32 = [d[k].astype(f32) for k in range(3)]
+            # degenerate directions: one component exactly 0, -0, denormal or 1e-30; the origin's matching coordinate
+            # sometimes exactly on a face of the box
+            k0 = rng.integers(0, 3, n)
+            special = rng.random(n) < 0.3
+            val = rng.choice(np.array([0.0, -0.0, 1e-41, -1e-41, 1e-30, -1e-30], dtype=f32), n)
+            for k in range(3):
+                sel = special & (k0 == k)
+                d32[k] = np.where(sel, val, d32[k]).astype(f32)
+                on_face = sel & (rng.random(n) < 0.2)
+                o32[k] = np.where(on_face, (lo[k] + f32(T[k])).astype(f32), o32[k]).astype(f32)
+            _, a, h, ncc, disc = terms(o32, d32, [c32[k][idx] for k in range(3)], (r.astype(f32)[idx] * r.astype(f32)[idx]).astype(f32))
+            accepted = (disc >= 0) & ((h > 0) | (ncc > 0))
+            assert accepted.sum() > 1000, (label, kind)
+            op = [(o32[k] - f32(T[k])).astype(f32) for k in range(3)]
+            for rcp_ulp in (-1, 0, 1):
+                reached = box_reached(lo, hi, op, d32, rcp_ulp)
+                dropped = accepted & ~reached
+                assert not dropped.any(), f"{label}, {kind}: {dropped.sum()} rays that can hit a sphere of a block do not reach the block's box"
+        if not layer:
+            # ... and worth having: rays from outside aimed four block sizes past the block do not reach its box
+            away = (dist > 8.0 * size[0, 0]) & ~inside
+            aim = centre[:, 0, :] + unit(rng, n) * 4.0 * 1.75 * size[0, 0]
+            d_off = [(aim[k] - o[k]).astype(f32) for k in range(3)]
+            op = [(o[k].astype(f32) - f32(T[k])).astype(f32) for k in range(3)]
+            assert box_reached(lo, hi, op, d_off)[away].mean() < 0.05, label
 
 
 def test_half_line_filter_on_bounce_rays_between_spheres():
