@@ -37,6 +37,7 @@ typedef struct RtLaunch {
     uint32_t pool_slots;       // rt_render_pool: open units per workgroup (LDS pool)
     uint32_t units_bottom_up;  // 1: the wavefronts take the launch's pixel units from the last row upwards
     float    scan_scale;       // sigma of the scan filter: a power of two, sigma * |c - o| <= 1/2 for origins on the scene's spheres
+    uint32_t sorted;           // 1: the device sphere list is sorted in space; the caller's indices follow the material tags
     uint32_t scan_blocks;      // blocks of 32 spheres with a bounding box (two float4 each after the n_padded filter entries); 0: none
     uint32_t ulist_cap;        // camera-ray-batch kernels: entries of a pixel unit's sphere list (even, <= 32: one mask of the scan; 0: no lists)
     float    unit_reach;       // how far a camera ray's direction can be from the one through the centre of its unit's footprint

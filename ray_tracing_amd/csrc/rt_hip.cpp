@@ -318,6 +318,7 @@ RtLaunch make_launch(const rt_ctx* c, const RtCamera* cam, const RtParams* p, ui
     }
     for (int k = 0; k < 3; k++) L.translate[k] = c->translate[k];
     L.scan_scale = c->scan_scale;
+    L.sorted = c->n_blocks != 0u ? 1u : 0u;
     L.scan_blocks = c->cull_boxes ? c->n_blocks : 0u;
     if (std::getenv("RT_EXP_NO_BOXES")) L.scan_blocks = 0u;                      // timing experiments only
     L.units_bottom_up = 0u;

@@ -142,6 +142,7 @@ __device__ unsigned long long* rt_dbg_ptr = nullptr;
 // told apart as the reference's loop over its list does, first one wins (library.cu:243-251).  The first line skips
 // the square root and the divides where no root can qualify: with t_min >= 0, a root beyond t_min needs
 // h > 0 or the origin inside the sphere (ncc > 0); otherwise sqrt(disc) <= |h| and both roots are <= 0.
+// orig = NULL: the device list is in the caller's order, and the first sphere met wins a tie by the strict bound alone.
 RT_DEV void accept_exact(float h, float ncc, float disc, float a, float t_min, int idx, const uint32_t* __restrict__ orig, Best& b) {
     if (disc >= 0.0f && (h > 0.0f || ncc > 0.0f)) {
 #ifdef RT_ABL_EXACT   // ablation (changes the image): what the exact test's IEEE square root and divides cost
@@ -166,7 +167,7 @@ RT_DEV void accept_exact(float h, float ncc, float disc, float a, float t_min, i
             root = root_b;
             ok = (t_min < root_b) && (root_b < b.t);
         }
-        if (root == b.t && b.idx >= 0 && t_min < root) ok = orig[idx] < orig[b.idx];   // a tie: the earlier sphere of the caller's list
+        if (orig && root == b.t && b.idx >= 0 && t_min < root) ok = orig[idx] < orig[b.idx];   // a tie: the earlier sphere of the caller's list
         if (ok) { b.t = root; b.idx = idx; }
     }
 }
@@ -186,6 +187,9 @@ RT_DEV void sphere_terms(float cx, float cy, float cz, float rr, V3 o, V3 d, flo
 // box: two float4 per block of 32 spheres (scan_tile), or NULL; orig: the caller's index of every device sphere (the
 // whole list's, whatever the tile)
 // tbox: two float4, the box around the whole tile's spheres (the kernels that stream the list), or NULL
+// The caller's index of every device sphere, behind the material tags -- where the launcher sorted the list (RtLaunch.sorted).
+RT_DEV const uint32_t* orig_of(const RtLaunch& L, const uint32_t* __restrict__ mat) { return L.sorted ? mat + L.n_padded : nullptr; }
+
 struct Tile { const float4* geo; const float4* exa; const float4* box; const uint32_t* orig; const float4* tbox; };
 
 // Per-lane list of candidate spheres of the tile being scanned, kept in LDS as a column of a
@@ -874,13 +878,13 @@ RT_DEV void render_body(const Scene& sc, uint32_t* __restrict__ rgba, float4* __
     const uint32_t n_items = L.max_depth > 0u ? P * L.n_chunks : 0u;   // per unit
     const bool exact_sum = L.n_chunks > 1u;
 
-    Tile tile = {rt_lds, rt_lds + tile_capacity(L), nullptr, sc.mat + L.n_padded};
+    Tile tile = {rt_lds, rt_lds + tile_capacity(L), nullptr, orig_of(L, sc.mat)};
     const V3 T = ld3(L.translate);
     // per wavefront and slot: [P][3] 64-bit words, fixed-point sums (exact_sum) or the fp32 run sum bits
     unsigned long long* accum = accum_base(L) + wave * (6u * P);
     for (uint32_t k = lane; k < 6u * P; k += 64u) accum[k] = 0ull;
     if (!MULTI) {
-        tile = stage_tile(L, sc.geom, sc.exact, sc.mat + L.n_padded, 0u, L.n_padded);
+        tile = stage_tile(L, sc.geom, sc.exact, orig_of(L, sc.mat), 0u, L.n_padded);
         __syncthreads();
     }
 
@@ -980,7 +984,7 @@ RT_DEV void render_body(const Scene& sc, uint32_t* __restrict__ rgba, float4* __
                 uint32_t count = L.n_padded - first;
                 if (count > RT_TILE_SPHERES) count = RT_TILE_SPHERES;
                 if (first) __syncthreads();                      // previous tile fully scanned
-                tile = stage_tile(L, sc.geom, sc.exact, sc.mat + L.n_padded, first, count);
+                tile = stage_tile(L, sc.geom, sc.exact, orig_of(L, sc.mat), first, count);
                 __syncthreads();
                 if (active) scan_tile<false>(tile, count, (int)first, T, L.scan_scale, o, d, a, L.t_min, b, cand, st);
             }
@@ -1273,7 +1277,7 @@ RT_DEV void render_queue_body(const Scene& sc, uint32_t* __restrict__ rgba, floa
     __syncthreads();
     // the exact-test data stays in global memory (8 KB, read a couple of times per ray, cached): with it in LDS
     // a compute unit holds four workgroups instead of five, measured 2 % slower on the 485-sphere scene
-    const Tile tile = {geo, sc.exact, L.scan_blocks ? box : nullptr, sc.mat + L.n_padded};
+    const Tile tile = {geo, sc.exact, L.scan_blocks ? box : nullptr, orig_of(L, sc.mat)};
 
     Stats st;
     Slot u0, u1;
@@ -1587,7 +1591,7 @@ RT_DEV void render_pool_body(const Scene& sc, uint32_t* __restrict__ rgba, float
     }
     for (uint32_t i = threadIdx.x; i < 2u * L.scan_blocks; i += blockDim.x) box[i] = sc.geom[S + i];
     __syncthreads();
-    const Tile tile = {geo, sc.exact, L.scan_blocks ? box : nullptr, sc.mat + L.n_padded};
+    const Tile tile = {geo, sc.exact, L.scan_blocks ? box : nullptr, orig_of(L, sc.mat)};
 
     Stats st;
     bool drained = false;
@@ -1757,7 +1761,7 @@ RT_DEV void render_queue_stream_body(const Scene& sc, uint32_t* __restrict__ rgb
     ul.terms = reinterpret_cast<float4*>(mine + RT_Q_CAND_CAP * 128u + 48u * P + RT_Q_WORDS * 256u);
     ul.idx = reinterpret_cast<uint16_t*>(ul.terms + L.ulist_cap);
     uint32_t ul_k = RT_UL_NONE;
-    const Tile whole = {geo, sc.exact, nullptr, sc.mat + L.n_padded};                           // exact-test data of the whole list, by sphere index
+    const Tile whole = {geo, sc.exact, nullptr, orig_of(L, sc.mat)};                           // exact-test data of the whole list, by sphere index
     for (uint32_t k = lane; k < 6u * P; k += 64u) accum[k] = 0ull;
     float4* fold = FOLD ? fold_all + (size_t)(blockIdx.x * (blockDim.x >> 6) + wave) * (2u * P * (size_t)L.samples_per_pixel) : nullptr;
     const float4* fold1 = FOLD ? fold + (size_t)P * L.samples_per_pixel : nullptr;
@@ -1834,7 +1838,7 @@ RT_DEV void render_queue_stream_body(const Scene& sc, uint32_t* __restrict__ rgb
                 else if (first / 16u + i < 2u * L.scan_blocks) box[i] = sc.geom[L.n_padded + first / 16u + i];
             }
             __syncthreads();
-            const Tile tile = {geo, sc.exact + first, box_f4 ? box : nullptr, sc.mat + L.n_padded, box_f4 ? box + (box_f4 - 2u) : nullptr};   // exact-test data from global memory
+            const Tile tile = {geo, sc.exact + first, box_f4 ? box : nullptr, orig_of(L, sc.mat), box_f4 ? box + (box_f4 - 2u) : nullptr};   // exact-test data from global memory
             if (active) scan_tile<true, true>(tile, count, (int)first, T, L.scan_scale, p.o, p.d, ra, L.t_min, b, cand, st);
         }
         if (active) {
@@ -2095,11 +2099,11 @@ rt_primary_hits(const float4* geom, const float4* exact, const uint32_t* mat, in
         uint32_t count = L.n_padded - first;
         if (count > RT_TILE_SPHERES) count = RT_TILE_SPHERES;
         if (first) __syncthreads();
-        Tile tile = stage_tile(L, geom, exact, mat + L.n_padded, first, count);
+        Tile tile = stage_tile(L, geom, exact, orig_of(L, mat), first, count);
         __syncthreads();
         if (valid) scan_tile<false>(tile, count, (int)first, ld3(L.translate), L.scan_scale, o, d, a, L.t_min, b, cand, st);
     }
-    if (valid) hits[(size_t)ly * L.width + x] = b.idx < 0 ? -1 : (int32_t)mat[L.n_padded + (uint32_t)b.idx];   // the caller's index
+    if (valid) hits[(size_t)ly * L.width + x] = b.idx < 0 ? -1 : L.sorted ? (int32_t)mat[L.n_padded + (uint32_t)b.idx] : b.idx;   // the caller's index
 }
 
 // ---------------------------------------------------------------- RNG debug views (ray.cu:114-118)
