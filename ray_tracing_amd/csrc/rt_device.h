@@ -75,6 +75,11 @@ typedef struct RtLaunch {
 #ifndef RT_Q_STREAM_TILE
 #define RT_Q_STREAM_TILE 512u
 #endif
+// A block of 32 spheres reached by at most this many lanes of a wavefront is scanned lanes-over-spheres, one reaching ray at
+// a time (scan_tile); beyond it the 64 rays scan the block's spheres side by side.
+#ifndef RT_SPARSE_MAX
+#define RT_SPARSE_MAX 8u
+#endif
 #define RT_Q_CAND_CAP 8u
 #define RT_Q_WORDS 8u
 // LDS bytes of a pixel unit's sphere list of `cap` entries: a float4 of camera-ray terms and a u16 index each

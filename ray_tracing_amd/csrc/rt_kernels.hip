@@ -52,9 +52,16 @@ struct Stats {
     uint32_t v[8];
     unsigned long long cyc[7], last;
     RT_DEV Stats() { for (int i = 0; i < 8; i++) v[i] = 0u; for (int i = 0; i < 7; i++) cyc[i] = 0ull; last = __builtin_amdgcn_s_memtime(); }
+#ifdef RT_STATS_REACH   // words 2..7 count block boxes instead: [2] tested, then reached by 1-2, 3-4, 5-8, 9-16, 17-64 lanes
+    RT_DEV void add(int, uint32_t) {}
+    RT_DEV void wave(int which) { if (which == 1) reach(1); }
+    RT_DEV void reach(int which) {
+#else
     RT_DEV void add(int which, uint32_t n) { v[which] += n; }
+    RT_DEV void reach(int) {}
     // counted once per wavefront: by the first lane that is active at the call
     RT_DEV void wave(int which) {
+#endif
         unsigned long long m = __ballot(1);
         if ((uint32_t)(__ffsll((long long)m) - 1) == (threadIdx.x & 63u)) v[which] += 1u;
     }
@@ -67,6 +74,7 @@ struct Stats {
 #else
     RT_DEV void add(int, uint32_t) {}
     RT_DEV void wave(int) {}
+    RT_DEV void reach(int) {}
     RT_DEV void lap(int) {}
 #endif
 };
@@ -330,9 +338,13 @@ RT_DEV void filter_step(const RayTerms& r, const float4* p, uint32_t& miss) {
     }
 }
 
+// act (BOXES builds only): the lane has a ray.  Those builds call the scan with EVERY lane of the wavefront (a 64-wide
+// instruction costs the same whatever the execution mask), because a block that few lanes reach is scanned the other
+// way round -- lanes over spheres, see below -- and that needs the lanes whatever they hold; a lane without a ray
+// reaches no box and lists nothing.
 template <bool HALF, bool BOXES = false>
 RT_DEV void scan_tile(const Tile& tile, uint32_t count, int base, V3 T, float sigma,
-                      V3 o, V3 d, float a, float t_min, Best& b, Cand& c, Stats& st) {
+                      V3 o, V3 d, float a, float t_min, Best& b, Cand& c, Stats& st, bool act = true) {
     st.wave(1);
     const V3 op = vsub(o, T);
     // Block boxes (tile.box != NULL): the list is sorted in space and every block of 32 spheres has a box outside
@@ -355,7 +367,7 @@ RT_DEV void scan_tile(const Tile& tile, uint32_t count, int base, V3 T, float si
             const float az = (lo.z - o_lo.z) * inv.z, bz = (hi.z - o_hi.z) * inv.z;
             const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
             const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
-            if (__ballot(!(tf < tn)) == 0ull) return;                  // (the lanes' candidate lists are empty between tiles)
+            if (__ballot(act && !(tf < tn)) == 0ull) return;           // (the lanes' candidate lists are empty between tiles)
         }
     }
     const float inv_len = filter_inv_len(a) * sigma;
@@ -367,6 +379,7 @@ RT_DEV void scan_tile(const Tile& tile, uint32_t count, int base, V3 T, float si
     r.k0 = -(vdot(op, op) * (1.0f - 0x1p-18f)) * s2;
     uint32_t blk = 0u;
     for (; blk + 32u <= count; blk += 32u) {                           // full blocks: one address, constant offsets
+        bool reach = act;                                              // this lane's ray can hit a sphere of the block
         if (BOXES && tile.box) {
             const float4 lo = tile.box[blk >> 4], hi = tile.box[(blk >> 4) + 1u];
             const float ax = (lo.x - o_lo.x) * inv.x, bx = (hi.x - o_hi.x) * inv.x;
@@ -375,7 +388,7 @@ RT_DEV void scan_tile(const Tile& tile, uint32_t count, int base, V3 T, float si
             const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
             const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
 #ifdef RT_BOXCHECK   // diagnostics: a lane whose ray misses the box but whose exact test accepts a sphere of the block
-            if (tf < tn) {
+            if (act && tf < tn) {
                 for (uint32_t j = 0; j < 32u; j++) {
                     const float4 e = tile.exa[blk + j];
                     float hh, nn, dd;
@@ -391,11 +404,51 @@ RT_DEV void scan_tile(const Tile& tile, uint32_t count, int base, V3 T, float si
                 }
             }
 #endif
-            if (__ballot(!(tf < tn)) == 0ull) continue;                // (anything that is not a number reaches the box)
+            reach = act && !(tf < tn);                                 // (anything that is not a number reaches the box)
+            const unsigned long long reached = __ballot(reach);
+#ifdef RT_STATS_REACH
+            { const uint32_t k = (uint32_t)__popcll(reached); st.reach(2); if (k) st.reach(k <= 2u ? 3 : k <= 4u ? 4 : k <= 8u ? 5 : k <= 16u ? 6 : 7); }
+#endif
+            if (reached == 0ull) continue;
+            if ((uint32_t)__popcll(reached) <= RT_SPARSE_MAX) {
+                // Few lanes reach the block (with 64 independent bounce rays most reached blocks are reached by one or
+                // two): the scan is turned round.  Lane j holds sphere blk + (j & 31) -- one 16-byte LDS read per lane
+                // instead of 32 broadcast reads -- and the reaching rays are taken one at a time, their eight filter terms
+                // read out of their lane into scalar registers: the same nine operations on the same numbers as
+                // filter_step, so the same keys bit for bit, for 32 spheres at once.  Some 25 instructions per reaching ray
+                // instead of 300 per block.
+                const float4 sp = tile.geo[blk + (threadIdx.x & 31u)];
+                uint32_t miss = 0xffffffffu;
+                unsigned long long todo = reached;
+                do {
+                    const int l = __ffsll((long long)todo) - 1;
+                    todo &= todo - 1ull;
+                    const float wx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r.w.x), l));
+                    const float wy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r.w.y), l));
+                    const float wz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r.w.z), l));
+                    const float k0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r.k0), l));
+                    const float ux = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r.uf.x), l));
+                    const float uy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r.uf.y), l));
+                    const float uz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r.uf.z), l));
+                    const float e0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r.e), l));
+                    const float t = fmaf(wz, sp.z, fmaf(wy, sp.y, fmaf(wx, sp.x, k0)));
+                    float g = fmaf(uz, sp.z, fmaf(uy, sp.y, fmaf(ux, sp.x, e0)));
+                    if (HALF) g = __builtin_amdgcn_fmed3f(g, 0.0f, 1.0f);
+                    const float key = fmaf(g, g, t) + sp.w;
+                    // bit j of the ballot: sphere blk + j is a candidate (sign bit of its key clear); the masks of
+                    // decode_block count the other way: bit j set = sphere blk + (31 - j) cannot be hit
+                    const uint32_t cand32 = (uint32_t)__ballot(__float_as_int(key) >= 0);
+                    if ((threadIdx.x & 63u) == (uint32_t)l) miss = ~__builtin_bitreverse32(cand32);
+                } while (todo != 0ull);
+                st.lap(9);
+                decode_block<false>(tile, base, blk, 32u, miss, nullptr, o, d, a, t_min, b, c, st);
+                continue;
+            }
         }
         uint32_t miss = 0u;                                            // bit j set: sphere blk + (31-j) cannot be hit
 #pragma unroll
         for (uint32_t i = 0; i < 32u; i += RT_SCAN_UNROLL) filter_step<HALF, RT_SCAN_UNROLL>(r, tile.geo + blk + i, miss);
+        if (BOXES && !reach) miss = 0xffffffffu;                       // nothing of this block for a lane that does not reach it
         st.lap(9);
         decode_block<false>(tile, base, blk, 32u, miss, nullptr, o, d, a, t_min, b, c, st);
     }
@@ -405,6 +458,7 @@ RT_DEV void scan_tile(const Tile& tile, uint32_t count, int base, V3 T, float si
         for (; i + RT_SCAN_UNROLL <= k; i += RT_SCAN_UNROLL) filter_step<HALF, RT_SCAN_UNROLL>(r, tile.geo + blk + i, miss);
         if (k & 4u) { filter_step<HALF, 4u>(r, tile.geo + blk + i, miss); i += 4u; }
         if (k & 2u) filter_step<HALF, 2u>(r, tile.geo + blk + i, miss);
+        if (BOXES && !act) miss = 0xffffffffu;
         st.lap(9);
         decode_block<false>(tile, base, blk, k, miss, nullptr, o, d, a, t_min, b, c, st);
     }
@@ -1350,11 +1404,12 @@ RT_DEV void render_queue_body(const Scene& sc, uint32_t* __restrict__ rgba, floa
 
         bool finished = false;                                   // this lane's path ended in this round
         st.lap(14);
+        Best b;
+        b.t = L.t_max;
+        b.idx = -1;
+        if (BOXES) scan_tile<true, true>(tile, S, 0, T, L.scan_scale, p.o, p.d, vdot(p.d, p.d), L.t_min, b, cand, st, active);   // every lane: see scan_tile
+        else if (active) scan_tile<true, false>(tile, S, 0, T, L.scan_scale, p.o, p.d, vdot(p.d, p.d), L.t_min, b, cand, st);
         if (active) {
-            Best b;
-            b.t = L.t_max;
-            b.idx = -1;
-            scan_tile<true, BOXES>(tile, S, 0, T, L.scan_scale, p.o, p.d, vdot(p.d, p.d), L.t_min, b, cand, st);
             nseg++;
             V3 color;
             if (shade_segment(sc, L, seed, b, pixel, s, band, p, color, st)) {
@@ -1668,11 +1723,12 @@ RT_DEV void render_pool_body(const Scene& sc, uint32_t* __restrict__ rgba, float
 
         bool finished = false;                                   // this lane's path ended in this round
         st.lap(14);
+        Best b;
+        b.t = L.t_max;
+        b.idx = -1;
+        if (BOXES) scan_tile<true, true>(tile, S, 0, T, L.scan_scale, p.o, p.d, vdot(p.d, p.d), L.t_min, b, cand, st, active);   // every lane: see scan_tile
+        else if (active) scan_tile<true, false>(tile, S, 0, T, L.scan_scale, p.o, p.d, vdot(p.d, p.d), L.t_min, b, cand, st);
         if (active) {
-            Best b;
-            b.t = L.t_max;
-            b.idx = -1;
-            scan_tile<true, BOXES>(tile, S, 0, T, L.scan_scale, p.o, p.d, vdot(p.d, p.d), L.t_min, b, cand, st);
             nseg++;
             V3 color;
             if (shade_segment(sc, L, seed, b, pixel, s, band, p, color, st)) {
@@ -1839,7 +1895,7 @@ RT_DEV void render_queue_stream_body(const Scene& sc, uint32_t* __restrict__ rgb
             }
             __syncthreads();
             const Tile tile = {geo, sc.exact + first, box_f4 ? box : nullptr, orig_of(L, sc.mat), box_f4 ? box + (box_f4 - 2u) : nullptr};   // exact-test data from global memory
-            if (active) scan_tile<true, true>(tile, count, (int)first, T, L.scan_scale, p.o, p.d, ra, L.t_min, b, cand, st);
+            scan_tile<true, true>(tile, count, (int)first, T, L.scan_scale, p.o, p.d, ra, L.t_min, b, cand, st, active);   // every lane: see scan_tile
         }
         if (active) {
             nseg++;
@@ -1863,6 +1919,15 @@ RT_DEV void render_queue_stream_body(const Scene& sc, uint32_t* __restrict__ rgb
         unsigned long long n64 = nseg;
         for (int off = 32; off > 0; off >>= 1) n64 += __shfl_xor(n64, off);
         if (lane == 0u && n64) atomicAdd(segments, n64);
+#ifdef RT_STATS
+        for (int w = 1; w < 8; w++) {
+            unsigned long long x = st.v[w];
+            for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
+            if (lane == 0u && x) atomicAdd(segments + w, x);
+        }
+        for (int w = 0; w < 7; w++)
+            if (lane == 0u) atomicAdd(segments + 9 + w, st.cyc[w]);
+#endif
     }
 }
 
