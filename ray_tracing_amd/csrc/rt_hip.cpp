@@ -725,6 +725,7 @@ int rt_upload_scene(rt_ctx* c, const RtSphere* spheres, uint32_t n) {
     // whatever their neighbours.  order[i] = the caller's index of device sphere i.
     std::vector<uint32_t> order(n);
     for (uint32_t i = 0; i < n; i++) order[i] = i;
+    uint32_t n_big = 0;                                              // sorted lists: the large spheres, first in `order`
     const bool sorted = n >= 128u && scene_radius > 0.0 && !std::getenv("RT_EXP_NO_SORT");   // (fewer: a scan costs less than the boxes' tests and registers)
     if (sorted) {
         float lo[3], hi[3];
@@ -758,10 +759,34 @@ int rt_upload_scene(rt_ctx* c, const RtSphere* spheres, uint32_t n) {
             }
             const bool big = std::fabs((double)spheres[i].radius) > extent / 8.0;
             const uint64_t morton = big ? 0u : (1ull << 30) | spread(q[0]) | (spread(q[1]) << 1) | (spread(q[2]) << 2);
+            if (big) n_big++;
             key[i] = (morton << 32) | i;
         }
         std::sort(key.begin(), key.end());
         for (uint32_t i = 0; i < n; i++) order[i] = (uint32_t)(key[i] & 0xffffffffu);
+    }
+    // Device slots.  A large sphere's box is reached by nearly every ray, and a block that holds one is scanned by all 64
+    // lanes of nearly every wavefront -- 32 spheres for the sake of one.  So the large spheres get the end of the list to
+    // themselves: the small ones in curve order, padding up to a whole block, then the large ones (padded to an even
+    // count): the scans' last, short step, which has no box and is taken by every lane.  slot[i] = the caller's index of
+    // device sphere i, or -1: padding (never a candidate, never hit).  Not done where it would push a list that fits one
+    // LDS tile beyond it, nor for more than 30 large spheres (they would fill a block anyway).
+    std::vector<int64_t> slot;
+    {
+        const uint32_t n_small = n - n_big;
+        const uint32_t small_padded = ((n_small + 31u) / 32u) * 32u;
+        const uint32_t apart = small_padded + ((n_big + pad - 1u) / pad) * pad;
+        const bool big_apart = sorted && n_big >= 1u && n_big <= 30u && n_small >= 32u && !(n_padded <= RT_TILE_SPHERES && apart > RT_TILE_SPHERES) &&
+                               !std::getenv("RT_EXP_BIG_FIRST");
+        if (big_apart) {
+            n_padded = apart;
+            slot.assign(n_padded, -1);
+            for (uint32_t i = 0; i < n_small; i++) slot[i] = order[n_big + i];
+            for (uint32_t i = 0; i < n_big; i++) slot[small_padded + i] = order[i];
+        } else {
+            slot.assign(n_padded, -1);
+            for (uint32_t i = 0; i < n; i++) slot[i] = order[i];
+        }
     }
     // after the spheres' filter data: per block of 32 spheres two float4, the corners of a box (coordinates relative to
     // T) that holds every point at which the exact test can report a hit of a sphere of the block, for rays leaving
@@ -780,11 +805,11 @@ int rt_upload_scene(rt_ctx* c, const RtSphere* spheres, uint32_t n) {
         float* g = &geom[4 * (size_t)i];
         float* x = &exact[4 * (size_t)i];
         float* s = &shade[8 * (size_t)i];
-        mat[(size_t)n_padded + i] = i < n ? order[i] : i;
-        if (i < n) {
-            const RtSphere& sp = spheres[order[i]];
+        mat[(size_t)n_padded + i] = slot[i] >= 0 ? (uint32_t)slot[i] : 0u;
+        if (slot[i] >= 0) {
+            const RtSphere& sp = spheres[slot[i]];
             if (sp.material < RT_MAT_DIFFUSE || sp.material > RT_MAT_DIELECTRIC)
-                return fail(c, RT_ERR_INVALID, "unknown material tag in sphere " + std::to_string(order[i]));
+                return fail(c, RT_ERR_INVALID, "unknown material tag in sphere " + std::to_string(slot[i]));
             const float rr = sp.radius * sp.radius;   // radius*radius, library.cu:203 / lib.rs:101
             double cc = 0.0;
             for (int k = 0; k < 3; k++) {
