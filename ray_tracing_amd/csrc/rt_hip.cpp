@@ -790,7 +790,7 @@ int rt_upload_scene(rt_ctx* c, const RtSphere* spheres, uint32_t n) {
     }
     // after the spheres' filter data: per block of 32 spheres two float4, the corners of a box (coordinates relative to
     // T) that holds every point at which the exact test can report a hit of a sphere of the block, for rays leaving
-    // from T: each sphere's own |r| (1 + 2^-10) + 2^-9 |c - T| + 2^-20 R beyond its centre (the kernel adds 2^-9 |o - T|
+    // from T: each sphere's own |r| (1 + 2^-10) + 2^-9 |c - T| + 2^-19 R beyond its centre (the kernel adds 2^-9 |o - T|
     // for its ray; the exact test's tolerance is below 2^-11 |c - o|)
     const uint32_t n_blocks = (n_padded + 31u) / 32u;
     const uint32_t n_tiles = (n_padded + RT_Q_STREAM_TILE - 1u) / RT_Q_STREAM_TILE;   // ... and one box per tile of the streaming kernels behind those
@@ -821,7 +821,7 @@ int rt_upload_scene(rt_ctx* c, const RtSphere* spheres, uint32_t n) {
             g[3] = std::nextafter((float)m, INFINITY) * (float)s2;   // times sigma^2, a power of two: exact
             {
                 float* lo4 = &geom[4 * ((size_t)n_padded + 2u * (i / 32u))];
-                const double ext = std::fabs((double)sp.radius) * (1.0 + 0x1p-10) + 0x1p-9 * std::sqrt(cc) + 0x1p-20 * (scene_radius > 0.0 ? scene_radius : 0.0);
+                const double ext = std::fabs((double)sp.radius) * (1.0 + 0x1p-10) + 0x1p-9 * std::sqrt(cc) + 0x1p-19 * (scene_radius > 0.0 ? scene_radius : 0.0);
                 for (int k = 0; k < 3; k++) {
                     const float a = std::nextafter((float)((double)g[k] - ext), -INFINITY), b = std::nextafter((float)((double)g[k] + ext), INFINITY);
                     if (!(a >= lo4[k])) lo4[k] = a;                   // (a NaN sticks: the box then never excludes anything)

@@ -347,29 +347,6 @@ RT_DEV void scan_tile(const Tile& tile, uint32_t count, int base, V3 T, float si
                       V3 o, V3 d, float a, float t_min, Best& b, Cand& c, Stats& st, bool act = true) {
     st.wave(1);
     const V3 op = vsub(o, T);
-    // Block boxes (tile.box != NULL): the list is sorted in space and every block of 32 spheres has a box outside
-    // which none of them can be hit; a block whose box no lane's half-line reaches is not scanned.  Slab test with
-    // the box grown by 2^-9 |o - T| for this ray (see the launcher: the exact test's tolerance).  A plane's parameter is
-    // (plane - o) / d, difference first: with d_k = 0 that is -inf or +inf on the right side of the origin (a product
-    // minus a product would be inf - inf there), and not a number only for an origin exactly in a plane of the grown
-    // box, where no sphere of the block is within reach.  minNum / maxNum drop what is not a number.
-    // tile.tbox: the same test for the whole tile first (a streamed list: most tiles are out of every lane's reach).
-    V3 inv = v3(0.0f, 0.0f, 0.0f), o_lo = v3(0.0f, 0.0f, 0.0f), o_hi = v3(0.0f, 0.0f, 0.0f);
-    if (BOXES && tile.box) {
-        inv = v3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
-        const float grow = __builtin_amdgcn_sqrtf(vdot(op, op)) * (0x1p-9f * (1.0f + 0x1p-10f));
-        o_lo = v3(op.x + grow, op.y + grow, op.z + grow);           // lower planes move down by `grow`: plane - (o + grow)
-        o_hi = v3(op.x - grow, op.y - grow, op.z - grow);
-        if (tile.tbox) {
-            const float4 lo = tile.tbox[0], hi = tile.tbox[1];
-            const float ax = (lo.x - o_lo.x) * inv.x, bx = (hi.x - o_hi.x) * inv.x;
-            const float ay = (lo.y - o_lo.y) * inv.y, by = (hi.y - o_hi.y) * inv.y;
-            const float az = (lo.z - o_lo.z) * inv.z, bz = (hi.z - o_hi.z) * inv.z;
-            const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
-            const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
-            if (__ballot(act && !(tf < tn)) == 0ull) return;           // (the lanes' candidate lists are empty between tiles)
-        }
-    }
     const float inv_len = filter_inv_len(a) * sigma;
     const float s2 = sigma * sigma;
     RayTerms r;
@@ -377,14 +354,44 @@ RT_DEV void scan_tile(const Tile& tile, uint32_t count, int base, V3 T, float si
     r.e = -vdot(r.uf, op);
     r.w = v3((2.0f * s2) * op.x, (2.0f * s2) * op.y, (2.0f * s2) * op.z);
     r.k0 = -(vdot(op, op) * (1.0f - 0x1p-18f)) * s2;
+    // Block boxes (tile.box != NULL): the list is sorted in space and every block of 32 spheres has a box outside
+    // which none of them can be hit; a block whose box no lane's half-line reaches is not scanned.  Slab test with
+    // the box grown by 2^-9 |o - T| for this ray (see the launcher: the exact test's tolerance).  A plane's parameter is
+    // (plane - o') / u_k = plane * inv_k - o' * inv_k: one fma per plane, the second product once per ray.  u = uf, the
+    // filter's scaled unit direction (any positive multiple of d serves: the test compares parameters with each other and
+    // with 0), and inv_k = 1 / u_k is clamped to +-2^40 / sigma -- as if no component of the unit direction were below
+    // 2^-40: over the scene's extent that moves the ray by less than 2^-37 R, which the boxes' own margin (2^-19 R)
+    // covers, and it keeps every product finite (1 / 0 = inf would give inf - inf for both planes of an axis the ray does
+    // not move along).  The roundings of the two-product form are below 2^-22 (|o'| + |plane|) in the plane's position,
+    // also within the margins (2^-9 |o'| (1 + 2^-8) here, 2^-19 R per sphere at upload).  minNum / maxNum drop what is
+    // not a number (only a NaN ray produces one).
+    // tile.tbox: the same test for the whole tile first (a streamed list: most tiles are out of every lane's reach).
+    V3 inv = v3(0.0f, 0.0f, 0.0f), n_lo = v3(0.0f, 0.0f, 0.0f), n_hi = v3(0.0f, 0.0f, 0.0f);
+    if (BOXES && tile.box) {
+        const float lim = 0x1p40f * __builtin_amdgcn_rcpf(sigma);
+        inv = v3(__builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(r.uf.x), -lim, lim), __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(r.uf.y), -lim, lim),
+                 __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(r.uf.z), -lim, lim));
+        const float grow = __builtin_amdgcn_sqrtf(vdot(op, op)) * (0x1p-9f * (1.0f + 0x1p-8f));
+        n_lo = v3(-(op.x + grow) * inv.x, -(op.y + grow) * inv.y, -(op.z + grow) * inv.z);   // lower planes move down by `grow`: plane - (o + grow)
+        n_hi = v3(-(op.x - grow) * inv.x, -(op.y - grow) * inv.y, -(op.z - grow) * inv.z);
+        if (tile.tbox) {
+            const float4 lo = tile.tbox[0], hi = tile.tbox[1];
+            const float ax = fmaf(lo.x, inv.x, n_lo.x), bx = fmaf(hi.x, inv.x, n_hi.x);
+            const float ay = fmaf(lo.y, inv.y, n_lo.y), by = fmaf(hi.y, inv.y, n_hi.y);
+            const float az = fmaf(lo.z, inv.z, n_lo.z), bz = fmaf(hi.z, inv.z, n_hi.z);
+            const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
+            const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+            if (__ballot(act && !(tf < tn)) == 0ull) return;           // (the lanes' candidate lists are empty between tiles)
+        }
+    }
     uint32_t blk = 0u;
     for (; blk + 32u <= count; blk += 32u) {                           // full blocks: one address, constant offsets
         bool reach = act;                                              // this lane's ray can hit a sphere of the block
         if (BOXES && tile.box) {
             const float4 lo = tile.box[blk >> 4], hi = tile.box[(blk >> 4) + 1u];
-            const float ax = (lo.x - o_lo.x) * inv.x, bx = (hi.x - o_hi.x) * inv.x;
-            const float ay = (lo.y - o_lo.y) * inv.y, by = (hi.y - o_hi.y) * inv.y;
-            const float az = (lo.z - o_lo.z) * inv.z, bz = (hi.z - o_hi.z) * inv.z;
+            const float ax = fmaf(lo.x, inv.x, n_lo.x), bx = fmaf(hi.x, inv.x, n_hi.x);
+            const float ay = fmaf(lo.y, inv.y, n_lo.y), by = fmaf(hi.y, inv.y, n_hi.y);
+            const float az = fmaf(lo.z, inv.z, n_lo.z), bz = fmaf(hi.z, inv.z, n_hi.z);
             const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
             const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
 #ifdef RT_BOXCHECK   // diagnostics: a lane whose ray misses the box but whose exact test accepts a sphere of the block

@@ -450,26 +450,40 @@ def test_unit_lists_hold_every_sphere_a_ray_of_the_unit_can_hit():
 # ---------------------------------------------------------------- block boxes (rt_upload_scene, scan_tile)
 def block_box(cp, r, R):
     """rt_upload_scene: the box of a block of spheres (arrays [members, blocks]) in coordinates relative to T: every
-    sphere's own |r| (1 + 2^-10) + 2^-9 |c'| + 2^-20 R beyond its centre, rounded outwards."""
+    sphere's own |r| (1 + 2^-10) + 2^-9 |c'| + 2^-19 R beyond its centre, rounded outwards."""
     cc = sum(cp[k].astype(np.float64) ** 2 for k in range(3))
-    ext = np.abs(r.astype(np.float64)) * (1.0 + 2.0 ** -10) + 2.0 ** -9 * np.sqrt(cc) + 2.0 ** -20 * R
+    ext = np.abs(r.astype(np.float64)) * (1.0 + 2.0 ** -10) + 2.0 ** -9 * np.sqrt(cc) + 2.0 ** -19 * R
     lo = [np.nextafter((cp[k].astype(np.float64) - ext).astype(f32), f32(-np.inf)).min(axis=0) for k in range(3)]
     hi = [np.nextafter((cp[k].astype(np.float64) + ext).astype(f32), f32(np.inf)).max(axis=0) for k in range(3)]
     return lo, hi
 
 
-def box_reached(lo, hi, op, d, rcp_ulp=0):
-    """scan_tile's slab test, operation for operation: the box grown by 2^-9 |o'| (1 + 2^-10) for this ray, a plane's
-    parameter (plane - o') * rcp(d), minNum / maxNum, the half-line t >= 0; reached unless tf < tn.  The hardware's
-    reciprocal is within 1 ulp (rcp_ulp moves it), its square root is modelled 2 ulps too small (a smaller box)."""
+def box_reached(lo, hi, op, d, rcp_ulp=0, sigma=1.0):
+    """scan_tile's slab test, operation for operation: the box grown by 2^-9 |o'| (1 + 2^-8) for this ray; a plane's
+    parameter fma(plane, inv, -(o' +- grow) inv) with inv = 1 / uf clamped to +-2^40 / sigma, uf = d rsq(d.d) (1 + 2^-19)
+    sigma the filter's scaled unit direction; minNum / maxNum, the half-line t >= 0; reached unless tf < tn.  The
+    hardware's reciprocal and 1/sqrt are within 1 ulp (rcp_ulp moves both), its square root is modelled 2 ulps too small
+    (a smaller box); a reciprocal's denormal argument counts as zero."""
     down = lambda x: np.nextafter(np.nextafter(x, f32(0.0)), f32(0.0))
-    with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
-        inv = [(f32(1.0) / d[k]).astype(f32) for k in range(3)]
+    sigma = f32(sigma)
+    with np.errstate(divide="ignore", invalid="ignore", over="ignore", under="ignore"):
+        a = dot(d, d)
+        rsq = (1.0 / np.sqrt(a.astype(np.float64))).astype(f32)
+        if rcp_ulp:
+            rsq = np.nextafter(rsq, f32(np.inf) if rcp_ulp > 0 else f32(0.0))
+        inv_len = ((rsq * f32(1.0 + 2.0 ** -19)).astype(f32) * sigma).astype(f32)
+        uf = [(d[k] * inv_len).astype(f32) for k in range(3)]
+        uf = [np.where(np.abs(x) < f32(2.0 ** -126), np.copysign(f32(0.0), x), x).astype(f32) for x in uf]
+        inv = [(f32(1.0) / uf[k]).astype(f32) for k in range(3)]
         if rcp_ulp:
             inv = [np.nextafter(x, np.where(x > 0, f32(np.inf), f32(-np.inf)).astype(f32) if rcp_ulp > 0 else f32(0.0)) for x in inv]
-        grow = (down(np.sqrt(dot(op, op))) * f32(2.0 ** -9 * (1.0 + 2.0 ** -10))).astype(f32)
-        a = [((lo[k] - (op[k] + grow).astype(f32)).astype(f32) * inv[k]).astype(f32) for k in range(3)]
-        b = [((hi[k] - (op[k] - grow).astype(f32)).astype(f32) * inv[k]).astype(f32) for k in range(3)]
+        lim = (f32(2.0 ** 40) * (f32(1.0) / sigma)).astype(f32)
+        inv = [np.where(np.isnan(x), -lim, np.clip(x, -lim, lim)).astype(f32) for x in inv]
+        grow = (down(np.sqrt(dot(op, op))) * f32(2.0 ** -9 * (1.0 + 2.0 ** -8))).astype(f32)
+        n_lo = [(-((op[k] + grow).astype(f32)) * inv[k]).astype(f32) for k in range(3)]
+        n_hi = [(-((op[k] - grow).astype(f32)) * inv[k]).astype(f32) for k in range(3)]
+        a = [fma(np.broadcast_to(lo[k], inv[k].shape).astype(f32), inv[k], n_lo[k]) for k in range(3)]
+        b = [fma(np.broadcast_to(hi[k], inv[k].shape).astype(f32), inv[k], n_hi[k]) for k in range(3)]
         tn = np.fmax(np.fmax(np.fmin(a[0], b[0]), np.fmin(a[1], b[1])), np.fmax(np.fmin(a[2], b[2]), f32(0.0)))
         tf = np.fmin(np.fmin(np.fmax(a[0], b[0]), np.fmax(a[1], b[1])), np.fmax(a[2], b[2]))
         return ~(tf < tn)
@@ -535,7 +549,7 @@ def test_block_boxes_are_reached_by_every_ray_that_can_hit_a_sphere_of_the_block
             assert accepted.sum() > 1000, (label, kind)
             op = [(o32[k] - f32(T[k])).astype(f32) for k in range(3)]
             for rcp_ulp in (-1, 0, 1):
-                reached = box_reached(lo, hi, op, d32, rcp_ulp)
+                reached = box_reached(lo, hi, op, d32, rcp_ulp, sigma=2.0 ** -np.frexp(4.0 * R)[1])
                 dropped = accepted & ~reached
                 assert not dropped.any(), f"{label}, {kind}: {dropped.sum()} rays that can hit a sphere of a block do not reach the block's box"
         if not layer:
@@ -544,7 +558,7 @@ def test_block_boxes_are_reached_by_every_ray_that_can_hit_a_sphere_of_the_block
             aim = centre[:, 0, :] + unit(rng, n) * 4.0 * 1.75 * size[0, 0]
             d_off = [(aim[k] - o[k]).astype(f32) for k in range(3)]
             op = [(o[k].astype(f32) - f32(T[k])).astype(f32) for k in range(3)]
-            assert box_reached(lo, hi, op, d_off)[away].mean() < 0.05, label
+            assert box_reached(lo, hi, op, d_off, sigma=2.0 ** -np.frexp(4.0 * R)[1])[away].mean() < 0.05, label
 
 
 def test_half_line_filter_on_bounce_rays_between_spheres():
