@@ -151,8 +151,23 @@ __device__ unsigned long long* rt_dbg_ptr = nullptr;
 // the square root and the divides where no root can qualify: with t_min >= 0, a root beyond t_min needs
 // h > 0 or the origin inside the sphere (ncc > 0); otherwise sqrt(disc) <= |h| and both roots are <= 0.
 // orig = NULL: the device list is in the caller's order, and the first sphere met wins a tie by the strict bound alone.
+// The sphere a bounce ray has just left is on every such ray's list (its origin is on the surface: "inside" to within the
+// filter's slack), and for half of them ncc comes out a rounding error above zero, with the centre behind the ray
+// (h <= 0).  Then only the far root (h + s) / a can lie beyond t_min, and it does not if
+//   disc <= K^2 (1 - 2^-19),  K = t_min a - h >= 0:
+// s = sqrt(disc) <= K (1 - 2^-22) even after its rounding, so h + s <= t_min a - 2^-22 K, rounded at most
+// t_min a (1 - 2^-23) (|h + s| <= K, K >= t_min a), and the quotient rounds below t_min: the exact test would reject, and
+// its square root and two divides are not needed (K, its square and the factor are rounded here: 4 x 2^-24 against the
+// 2^-20 to spare).  With a = 0 the condition holds only for h = 0, where the roots are 0 / 0.
 RT_DEV void accept_exact(float h, float ncc, float disc, float a, float t_min, int idx, const uint32_t* __restrict__ orig, Best& b) {
-    if (disc >= 0.0f && (h > 0.0f || ncc > 0.0f)) {
+    bool maybe = disc >= 0.0f && (h > 0.0f || ncc > 0.0f);
+#ifndef RT_EXP_NO_LEFT_TEST
+    if (maybe && !(h > 0.0f)) {
+        const float k = fmaf(t_min, a, -h);
+        maybe = !(disc <= k * k * (1.0f - 0x1p-19f));
+    }
+#endif
+    if (maybe) {
 #ifdef RT_ABL_EXACT   // ablation (changes the image): what the exact test's IEEE square root and divides cost
         float s = __builtin_amdgcn_sqrtf(disc);
         const float ia = __builtin_amdgcn_rcpf(a);
