@@ -80,6 +80,10 @@ typedef struct RtLaunch {
 #ifndef RT_SPARSE_MAX
 #define RT_SPARSE_MAX 8u
 #endif
+// ... and a streamed tile reached by at most this many lanes has the boxes of its blocks tested lanes-over-blocks
+#ifndef RT_SPARSE_TILE_MAX
+#define RT_SPARSE_TILE_MAX 12u
+#endif
 #define RT_Q_CAND_CAP 8u
 #define RT_Q_WORDS 8u
 // LDS bytes of a pixel unit's sphere list of `cap` entries: a float4 of camera-ray terms and a u16 index each

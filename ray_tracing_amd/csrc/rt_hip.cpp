@@ -413,7 +413,7 @@ int launch_render(rt_ctx* c, const RtCamera* cam, const RtParams* p, RtLaunch L,
         }
         // the unit lists are the first thing to go where a workgroup's LDS (64 KiB) is short: 16 entries, 12, 8, none
         auto queue_lds = [&](unsigned cap) {
-            return (one_tile ? c->n_padded * 32u + L.scan_blocks * 32u : RT_Q_STREAM_TILE * 16u + (L.scan_blocks ? RT_Q_STREAM_TILE + 32u : 0u)) +
+            return (one_tile ? c->n_padded * 32u + L.scan_blocks * 32u : RT_Q_STREAM_TILE * 16u + (L.scan_blocks ? RT_Q_STREAM_TILE + 32u + 16u : 0u)) +
                    waves * (RT_Q_CAND_CAP * 128u + 48u * P + RT_Q_WORDS * 256u + RT_UL_BYTES(cap));
         };
         auto pool_lds = [&](unsigned cap) {

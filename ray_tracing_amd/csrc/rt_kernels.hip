@@ -52,6 +52,7 @@ struct Stats {
     uint32_t v[8];
     unsigned long long cyc[7], last;
     RT_DEV Stats() { for (int i = 0; i < 8; i++) v[i] = 0u; for (int i = 0; i < 7; i++) cyc[i] = 0ull; last = __builtin_amdgcn_s_memtime(); }
+    RT_DEV void raw(int which, uint32_t n) { v[which] += n; }
 #ifdef RT_STATS_REACH   // words 2..7 count block boxes instead: [2] tested, then reached by 1-2, 3-4, 5-8, 9-16, 17-64 lanes
     RT_DEV void add(int, uint32_t) {}
     RT_DEV void wave(int which) { if (which == 1) reach(1); }
@@ -73,6 +74,7 @@ struct Stats {
     }
 #else
     RT_DEV void add(int, uint32_t) {}
+    RT_DEV void raw(int, uint32_t) {}
     RT_DEV void wave(int) {}
     RT_DEV void reach(int) {}
     RT_DEV void lap(int) {}
@@ -353,6 +355,78 @@ RT_DEV void filter_step(const RayTerms& r, const float4* p, uint32_t& miss) {
     }
 }
 
+// A block of 32 spheres that few lanes reach (with 64 independent bounce rays most reached blocks are reached by one or
+// two) is scanned the other way round.  Lane j holds sphere (j & 31) of the block -- one 16-byte LDS read per lane
+// instead of 32 broadcast reads -- and the reaching rays (`reached`: their lanes) are taken one at a time, their eight
+// filter terms read out of their lane into scalar registers: the same nine operations on the same numbers as
+// filter_step, so the same keys bit for bit, for 32 spheres at once.  Some 25 instructions per reaching ray instead of
+// 300 per block.  Called by the whole wavefront; returns the lane's mask as filter_step builds it (all ones for a
+// lane that does not reach the block).
+template <bool HALF>
+RT_DEV uint32_t sparse_block(const RayTerms& r, const float4* geo_blk, unsigned long long reached) {
+    const float4 sp = geo_blk[threadIdx.x & 31u];
+    uint32_t miss = 0xffffffffu;
+    unsigned long long todo = reached;
+    while (todo != 0ull) {
+        const int l = __ffsll((long long)todo) - 1;
+        todo &= todo - 1ull;
+        const float wx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r.w.x), l));
+        const float wy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r.w.y), l));
+        const float wz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r.w.z), l));
+        const float k0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r.k0), l));
+        const float ux = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r.uf.x), l));
+        const float uy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r.uf.y), l));
+        const float uz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r.uf.z), l));
+        const float e0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r.e), l));
+        const float t = fmaf(wz, sp.z, fmaf(wy, sp.y, fmaf(wx, sp.x, k0)));
+        float g = fmaf(uz, sp.z, fmaf(uy, sp.y, fmaf(ux, sp.x, e0)));
+        if (HALF) g = __builtin_amdgcn_fmed3f(g, 0.0f, 1.0f);
+        const float key = fmaf(g, g, t) + sp.w;
+        // bit j of the ballot: sphere j of the block is a candidate (sign bit of its key clear); the masks of
+        // decode_block count the other way: bit j set = sphere 31 - j cannot be hit
+        const uint32_t cand32 = (uint32_t)__ballot(__float_as_int(key) >= 0);
+        if ((threadIdx.x & 63u) == (uint32_t)l) miss = ~__builtin_bitreverse32(cand32);
+    }
+    return miss;
+}
+
+// Slab test of a ray's half-line against a box {lo, hi} (coordinates relative to T), see scan_tile.
+struct BoxTerms { V3 inv, n_lo, n_hi; };
+RT_DEV BoxTerms box_terms(V3 op, V3 uf, float sigma) {
+    BoxTerms bt;
+    const float lim = 0x1p40f * __builtin_amdgcn_rcpf(sigma);
+    bt.inv = v3(__builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(uf.x), -lim, lim), __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(uf.y), -lim, lim),
+                __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(uf.z), -lim, lim));
+    const float grow = __builtin_amdgcn_sqrtf(vdot(op, op)) * (0x1p-9f * (1.0f + 0x1p-8f));
+    bt.n_lo = v3(-(op.x + grow) * bt.inv.x, -(op.y + grow) * bt.inv.y, -(op.z + grow) * bt.inv.z);   // lower planes move down by `grow`: plane - (o + grow)
+    bt.n_hi = v3(-(op.x - grow) * bt.inv.x, -(op.y - grow) * bt.inv.y, -(op.z - grow) * bt.inv.z);
+    return bt;
+}
+// tn, tf: where the half-line enters and leaves the box; it reaches the box unless tf < tn
+RT_DEV void box_span(const BoxTerms& bt, float4 lo, float4 hi, float& tn, float& tf) {
+    const float ax = fmaf(lo.x, bt.inv.x, bt.n_lo.x), bx = fmaf(hi.x, bt.inv.x, bt.n_hi.x);
+    const float ay = fmaf(lo.y, bt.inv.y, bt.n_lo.y), by = fmaf(hi.y, bt.inv.y, bt.n_hi.y);
+    const float az = fmaf(lo.z, bt.inv.z, bt.n_lo.z), bz = fmaf(hi.z, bt.inv.z, bt.n_hi.z);
+    tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
+    tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+}
+// the filter's scaled unit direction of a ray (scan_tile)
+RT_DEV V3 filter_dir(V3 d, float a, float sigma) {
+    const float inv_len = filter_inv_len(a) * sigma;
+    return v3(d.x * inv_len, d.y * inv_len, d.z * inv_len);
+}
+
+// the filter's per-ray constants (scan_tile); op = o - T
+RT_DEV RayTerms ray_terms(V3 op, V3 d, float a, float sigma) {
+    const float s2 = sigma * sigma;
+    RayTerms r;
+    r.uf = filter_dir(d, a, sigma);
+    r.e = -vdot(r.uf, op);
+    r.w = v3((2.0f * s2) * op.x, (2.0f * s2) * op.y, (2.0f * s2) * op.z);
+    r.k0 = -(vdot(op, op) * (1.0f - 0x1p-18f)) * s2;
+    return r;
+}
+
 // act (BOXES builds only): the lane has a ray.  Those builds call the scan with EVERY lane of the wavefront (a 64-wide
 // instruction costs the same whatever the execution mask), because a block that few lanes reach is scanned the other
 // way round -- lanes over spheres, see below -- and that needs the lanes whatever they hold; a lane without a ray
@@ -362,13 +436,7 @@ RT_DEV void scan_tile(const Tile& tile, uint32_t count, int base, V3 T, float si
                       V3 o, V3 d, float a, float t_min, Best& b, Cand& c, Stats& st, bool act = true) {
     st.wave(1);
     const V3 op = vsub(o, T);
-    const float inv_len = filter_inv_len(a) * sigma;
-    const float s2 = sigma * sigma;
-    RayTerms r;
-    r.uf = v3(d.x * inv_len, d.y * inv_len, d.z * inv_len);
-    r.e = -vdot(r.uf, op);
-    r.w = v3((2.0f * s2) * op.x, (2.0f * s2) * op.y, (2.0f * s2) * op.z);
-    r.k0 = -(vdot(op, op) * (1.0f - 0x1p-18f)) * s2;
+    const RayTerms r = ray_terms(op, d, a, sigma);
     // Block boxes (tile.box != NULL): the list is sorted in space and every block of 32 spheres has a box outside
     // which none of them can be hit; a block whose box no lane's half-line reaches is not scanned.  Slab test with
     // the box grown by 2^-9 |o - T| for this ray (see the launcher: the exact test's tolerance).  A plane's parameter is
@@ -381,21 +449,13 @@ RT_DEV void scan_tile(const Tile& tile, uint32_t count, int base, V3 T, float si
     // also within the margins (2^-9 |o'| (1 + 2^-8) here, 2^-19 R per sphere at upload).  minNum / maxNum drop what is
     // not a number (only a NaN ray produces one).
     // tile.tbox: the same test for the whole tile first (a streamed list: most tiles are out of every lane's reach).
-    V3 inv = v3(0.0f, 0.0f, 0.0f), n_lo = v3(0.0f, 0.0f, 0.0f), n_hi = v3(0.0f, 0.0f, 0.0f);
+    BoxTerms bt;
+    bt.inv = bt.n_lo = bt.n_hi = v3(0.0f, 0.0f, 0.0f);
     if (BOXES && tile.box) {
-        const float lim = 0x1p40f * __builtin_amdgcn_rcpf(sigma);
-        inv = v3(__builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(r.uf.x), -lim, lim), __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(r.uf.y), -lim, lim),
-                 __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(r.uf.z), -lim, lim));
-        const float grow = __builtin_amdgcn_sqrtf(vdot(op, op)) * (0x1p-9f * (1.0f + 0x1p-8f));
-        n_lo = v3(-(op.x + grow) * inv.x, -(op.y + grow) * inv.y, -(op.z + grow) * inv.z);   // lower planes move down by `grow`: plane - (o + grow)
-        n_hi = v3(-(op.x - grow) * inv.x, -(op.y - grow) * inv.y, -(op.z - grow) * inv.z);
+        bt = box_terms(op, r.uf, sigma);
         if (tile.tbox) {
-            const float4 lo = tile.tbox[0], hi = tile.tbox[1];
-            const float ax = fmaf(lo.x, inv.x, n_lo.x), bx = fmaf(hi.x, inv.x, n_hi.x);
-            const float ay = fmaf(lo.y, inv.y, n_lo.y), by = fmaf(hi.y, inv.y, n_hi.y);
-            const float az = fmaf(lo.z, inv.z, n_lo.z), bz = fmaf(hi.z, inv.z, n_hi.z);
-            const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
-            const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+            float tn, tf;
+            box_span(bt, tile.tbox[0], tile.tbox[1], tn, tf);
             if (__ballot(act && !(tf < tn)) == 0ull) return;           // (the lanes' candidate lists are empty between tiles)
         }
     }
@@ -404,11 +464,8 @@ RT_DEV void scan_tile(const Tile& tile, uint32_t count, int base, V3 T, float si
         bool reach = act;                                              // this lane's ray can hit a sphere of the block
         if (BOXES && tile.box) {
             const float4 lo = tile.box[blk >> 4], hi = tile.box[(blk >> 4) + 1u];
-            const float ax = fmaf(lo.x, inv.x, n_lo.x), bx = fmaf(hi.x, inv.x, n_hi.x);
-            const float ay = fmaf(lo.y, inv.y, n_lo.y), by = fmaf(hi.y, inv.y, n_hi.y);
-            const float az = fmaf(lo.z, inv.z, n_lo.z), bz = fmaf(hi.z, inv.z, n_hi.z);
-            const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
-            const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+            float tn, tf;
+            box_span(bt, lo, hi, tn, tf);
 #ifdef RT_BOXCHECK   // diagnostics: a lane whose ray misses the box but whose exact test accepts a sphere of the block
             if (act && tf < tn) {
                 for (uint32_t j = 0; j < 32u; j++) {
@@ -433,35 +490,7 @@ RT_DEV void scan_tile(const Tile& tile, uint32_t count, int base, V3 T, float si
 #endif
             if (reached == 0ull) continue;
             if ((uint32_t)__popcll(reached) <= RT_SPARSE_MAX) {
-                // Few lanes reach the block (with 64 independent bounce rays most reached blocks are reached by one or
-                // two): the scan is turned round.  Lane j holds sphere blk + (j & 31) -- one 16-byte LDS read per lane
-                // instead of 32 broadcast reads -- and the reaching rays are taken one at a time, their eight filter terms
-                // read out of their lane into scalar registers: the same nine operations on the same numbers as
-                // filter_step, so the same keys bit for bit, for 32 spheres at once.  Some 25 instructions per reaching ray
-                // instead of 300 per block.
-                const float4 sp = tile.geo[blk + (threadIdx.x & 31u)];
-                uint32_t miss = 0xffffffffu;
-                unsigned long long todo = reached;
-                do {
-                    const int l = __ffsll((long long)todo) - 1;
-                    todo &= todo - 1ull;
-                    const float wx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r.w.x), l));
-                    const float wy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r.w.y), l));
-                    const float wz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r.w.z), l));
-                    const float k0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r.k0), l));
-                    const float ux = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r.uf.x), l));
-                    const float uy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r.uf.y), l));
-                    const float uz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r.uf.z), l));
-                    const float e0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r.e), l));
-                    const float t = fmaf(wz, sp.z, fmaf(wy, sp.y, fmaf(wx, sp.x, k0)));
-                    float g = fmaf(uz, sp.z, fmaf(uy, sp.y, fmaf(ux, sp.x, e0)));
-                    if (HALF) g = __builtin_amdgcn_fmed3f(g, 0.0f, 1.0f);
-                    const float key = fmaf(g, g, t) + sp.w;
-                    // bit j of the ballot: sphere blk + j is a candidate (sign bit of its key clear); the masks of
-                    // decode_block count the other way: bit j set = sphere blk + (31 - j) cannot be hit
-                    const uint32_t cand32 = (uint32_t)__ballot(__float_as_int(key) >= 0);
-                    if ((threadIdx.x & 63u) == (uint32_t)l) miss = ~__builtin_bitreverse32(cand32);
-                } while (todo != 0ull);
+                const uint32_t miss = sparse_block<HALF>(r, tile.geo + blk, reached);
                 st.lap(9);
                 decode_block<false>(tile, base, blk, 32u, miss, nullptr, o, d, a, t_min, b, c, st);
                 continue;
@@ -481,6 +510,98 @@ RT_DEV void scan_tile(const Tile& tile, uint32_t count, int base, V3 T, float si
         if (k & 4u) { filter_step<HALF, 4u>(r, tile.geo + blk + i, miss); i += 4u; }
         if (k & 2u) filter_step<HALF, 2u>(r, tile.geo + blk + i, miss);
         if (BOXES && !act) miss = 0xffffffffu;
+        st.lap(9);
+        decode_block<false>(tile, base, blk, k, miss, nullptr, o, d, a, t_min, b, c, st);
+    }
+    drain(tile, base, c, o, d, a, t_min, b, st);
+    st.lap(11);
+}
+
+// scan_tile for one staged tile of a streamed list (whole blocks, plus a short last step behind them where the list
+// ends), for the lanes whose ray reaches the tile's box (`tile_reach`; the caller has tested it and calls only if some
+// lane does).  The blocks' boxes are tested the way sparse_block scans: where at most RT_SPARSE_TILE_MAX lanes reach
+// the tile, lane j holds the box of block (j & 15) and the reaching rays are taken one at a time, their nine slab
+// terms in scalar registers -- 30 instructions per reaching ray instead of 25 per block for all 64 lanes; then only
+// the blocks somebody reaches are visited at all.
+RT_DEV void scan_tile_stream(const Tile& tile, uint32_t count, int base, const RayTerms& r, const BoxTerms& bt, V3 o, V3 d, float a,
+                             float t_min, Best& b, Cand& c, Stats& st, bool act, bool tile_reach) {
+    st.wave(1);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t n_full = count >> 5;                               // <= 16: RT_Q_STREAM_TILE / 32
+    const unsigned long long tr = __ballot(tile_reach);
+    uint32_t mine = 0u;                                               // bit j: this lane's ray reaches block j of the tile
+    uint32_t anybody = 0u;                                            // ... some lane's does (wave-uniform)
+    if ((uint32_t)__popcll(tr) <= RT_SPARSE_TILE_MAX) {
+        const uint32_t jb = lane & 15u;
+        const float4 lo = tile.box[2u * jb], hi = tile.box[2u * jb + 1u];
+        unsigned long long todo = tr;
+        while (todo != 0ull) {
+            const int l = __ffsll((long long)todo) - 1;
+            todo &= todo - 1ull;
+            BoxTerms q;
+            q.inv = v3(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(bt.inv.x), l)), __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bt.inv.y), l)),
+                       __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bt.inv.z), l)));
+            q.n_lo = v3(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(bt.n_lo.x), l)), __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bt.n_lo.y), l)),
+                        __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bt.n_lo.z), l)));
+            q.n_hi = v3(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(bt.n_hi.x), l)), __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bt.n_hi.y), l)),
+                        __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bt.n_hi.z), l)));
+            float tn, tf;
+            box_span(q, lo, hi, tn, tf);
+            const uint32_t m16 = (uint32_t)__ballot(jb < n_full && !(tf < tn)) & 0xffffu;   // (lanes 16..63 repeat lanes 0..15)
+            anybody |= m16;
+            if (lane == (uint32_t)l) mine = m16;
+        }
+    } else {
+        for (uint32_t j = 0u; j < n_full; j++) {
+            float tn, tf;
+            box_span(bt, tile.box[2u * j], tile.box[2u * j + 1u], tn, tf);
+            const bool reach = tile_reach && !(tf < tn);
+            if (reach) mine |= 1u << j;
+            if (__ballot(reach) != 0ull) anybody |= 1u << j;
+        }
+    }
+#ifdef RT_BOXCHECK   // diagnostics: a lane whose ray is kept off a block but whose exact test accepts a sphere of it
+    if (act)
+        for (uint32_t j = 0u; j < n_full; j++)
+            if (!((mine >> j) & 1u))
+                for (uint32_t i = 0; i < 32u; i++) {
+                    const float4 e = tile.exa[32u * j + i];
+                    float hh, nn, dd;
+                    sphere_terms(e.x, e.y, e.z, e.w, o, d, a, hh, nn, dd);
+                    Best tmp; tmp.t = INFINITY; tmp.idx = -1;
+                    accept_exact(hh, nn, dd, a, t_min, (int)(32u * j + i), tile.orig, tmp);
+                    if (tmp.idx >= 0 && rt_dbg_ptr) {
+                        float* w = reinterpret_cast<float*>(rt_dbg_ptr + 1);
+                        w[0] = o.x; w[1] = o.y; w[2] = o.z; w[3] = d.x; w[4] = d.y; w[5] = d.z;
+                        w[6] = (float)(base + (int)(32u * j + i)); w[7] = tmp.t;
+                    }
+                }
+#endif
+    while (anybody != 0u) {
+        const uint32_t j = (uint32_t)__builtin_ctz(anybody);
+        anybody &= anybody - 1u;
+        const uint32_t blk = 32u * j;
+        const bool reach = ((mine >> j) & 1u) != 0u;
+        const unsigned long long reached = __ballot(reach);
+        uint32_t miss;
+        if ((uint32_t)__popcll(reached) <= RT_SPARSE_MAX) {
+            miss = sparse_block<true>(r, tile.geo + blk, reached);
+        } else {
+            miss = 0u;
+#pragma unroll
+            for (uint32_t i = 0; i < 32u; i += RT_SCAN_UNROLL) filter_step<true, RT_SCAN_UNROLL>(r, tile.geo + blk + i, miss);
+            if (!reach) miss = 0xffffffffu;
+        }
+        st.lap(9);
+        decode_block<false>(tile, base, blk, 32u, miss, nullptr, o, d, a, t_min, b, c, st);
+    }
+    if (count & 31u) {                                                 // the list's last 2 .. 30 spheres: no box, every lane with a ray
+        const uint32_t blk = 32u * n_full, k = count - blk;
+        uint32_t miss = 0u, i = 0u;
+        for (; i + RT_SCAN_UNROLL <= k; i += RT_SCAN_UNROLL) filter_step<true, RT_SCAN_UNROLL>(r, tile.geo + blk + i, miss);
+        if (k & 4u) { filter_step<true, 4u>(r, tile.geo + blk + i, miss); i += 4u; }
+        if (k & 2u) filter_step<true, 2u>(r, tile.geo + blk + i, miss);
+        if (!act) miss = 0xffffffffu;
         st.lap(9);
         decode_block<false>(tile, base, blk, k, miss, nullptr, o, d, a, t_min, b, c, st);
     }
@@ -1825,7 +1946,9 @@ RT_DEV void render_queue_stream_body(const Scene& sc, uint32_t* __restrict__ rgb
     float4* geo = rt_lds;
     float4* box = geo + S;                                        // the boxes of the tile's blocks (scan_tile), 2 x S / 32
     const uint32_t box_f4 = L.scan_blocks ? 2u * (S / 32u) + 2u : 0u;   // ... and the tile's own box behind them
-    char* mine = reinterpret_cast<char*>(box + box_f4) + wave * (RT_Q_CAND_CAP * 128u + 48u * P + RT_Q_WORDS * 256u + RT_UL_BYTES(L.ulist_cap));
+    // ... and two 64-bit words in which the wavefronts vote on the tiles of a round (below)
+    unsigned long long* vote = reinterpret_cast<unsigned long long*>(box + box_f4);
+    char* mine = reinterpret_cast<char*>(box + box_f4 + (box_f4 ? 1u : 0u)) + wave * (RT_Q_CAND_CAP * 128u + 48u * P + RT_Q_WORDS * 256u + RT_UL_BYTES(L.ulist_cap));
     Cand cand;
     cand.col = reinterpret_cast<uint16_t*>(mine) + lane;
     cand.n = 0u;
@@ -1844,6 +1967,8 @@ RT_DEV void render_queue_stream_body(const Scene& sc, uint32_t* __restrict__ rgb
     float4* fold = FOLD ? fold_all + (size_t)(blockIdx.x * (blockDim.x >> 6) + wave) * (2u * P * (size_t)L.samples_per_pixel) : nullptr;
     const float4* fold1 = FOLD ? fold + (size_t)P * L.samples_per_pixel : nullptr;
 
+    if (box_f4 && threadIdx.x == 0u) { vote[0] = 0ull; vote[1] = 0ull; }   // (the first round's barrier comes before the first vote)
+    uint32_t round = 0u;
     Stats st;
     Slot u0, u1;
     u0.open = u1.open = false;
@@ -1906,10 +2031,44 @@ RT_DEV void render_queue_stream_body(const Scene& sc, uint32_t* __restrict__ rgb
         b.idx = -1;
         bool finished = false;                                   // a bounce path of this lane ended in this round
         const float ra = vdot(p.d, p.d);
-        for (uint32_t first = 0u; first < L.n_padded; first += RT_Q_STREAM_TILE) {
+        // Which tiles does anybody need?  Every lane tests its ray against the boxes of all tiles (wave-uniform reads
+        // from global memory), the wavefronts put their answers together in LDS, and a tile nobody's ray reaches is
+        // neither staged nor waited for: one barrier for the vote instead of two per tile (the first 64 tiles; any
+        // beyond are staged as before).  The two vote words take turns: the one not in use is cleared after the
+        // barrier, a round before it is voted in again.
+        unsigned long long needed = ~0ull;
+        unsigned long long lane_tiles = 0ull, mine_need = 0ull;     // tiles this lane's ray reaches; tiles some lane of this wavefront reaches
+        const V3 op = vsub(p.o, T);
+        const RayTerms rterms = ray_terms(op, p.d, ra, L.scan_scale);
+        BoxTerms bt;
+        bt.inv = bt.n_lo = bt.n_hi = v3(0.0f, 0.0f, 0.0f);
+        if (box_f4) {
+            bt = box_terms(op, rterms.uf, L.scan_scale);
+            const float4* tboxes = sc.geom + L.n_padded + 2u * L.scan_blocks;
+            const uint32_t n_tiles = (L.n_padded + RT_Q_STREAM_TILE - 1u) / RT_Q_STREAM_TILE;
+            for (uint32_t t = 0u; t < n_tiles && t < 64u; t++) {
+                float tn, tf;
+                box_span(bt, tboxes[2u * t], tboxes[2u * t + 1u], tn, tf);
+                const bool reach = active && !(tf < tn);
+                if (reach) lane_tiles |= 1ull << t;
+                if (__ballot(reach) != 0ull) mine_need |= 1ull << t;
+            }
+            if (lane == 0u && mine_need != 0ull) atomicOr(&vote[round & 1u], mine_need);
+            __syncthreads();
+            needed = vote[round & 1u];
+            if (threadIdx.x == 0u) vote[(round & 1u) ^ 1u] = 0ull;
+            round++;
+#ifdef RT_STATS_VOTE
+            if (threadIdx.x == 0u) { st.raw(5, (uint32_t)__popcll(needed)); st.raw(7, 1u); st.raw(6, (uint32_t)__popcll(mine_need)); }
+#endif
+        }
+        bool staged = false;
+        for (uint32_t first = 0u, t = 0u; first < L.n_padded; first += RT_Q_STREAM_TILE, t++) {
             uint32_t count = L.n_padded - first;
             if (count > RT_Q_STREAM_TILE) count = RT_Q_STREAM_TILE;
-            if (first) __syncthreads();                          // previous tile fully scanned
+            if (t < 64u && !((needed >> t) & 1ull)) continue;    // (the same for the whole workgroup)
+            if (staged) __syncthreads();                         // previous tile fully scanned
+            staged = true;
             for (uint32_t i = threadIdx.x; i < count; i += blockDim.x) geo[i] = sc.geom[first + i];
             for (uint32_t i = threadIdx.x; i < box_f4; i += blockDim.x) {   // (2 float4 per 32 spheres, then the tile's own two)
                 if (i >= box_f4 - 2u) box[i] = sc.geom[L.n_padded + 2u * L.scan_blocks + 2u * (first / S) + (i - (box_f4 - 2u))];
@@ -1917,7 +2076,9 @@ RT_DEV void render_queue_stream_body(const Scene& sc, uint32_t* __restrict__ rgb
             }
             __syncthreads();
             const Tile tile = {geo, sc.exact + first, box_f4 ? box : nullptr, orig_of(L, sc.mat), box_f4 ? box + (box_f4 - 2u) : nullptr};   // exact-test data from global memory
-            scan_tile<true, true>(tile, count, (int)first, T, L.scan_scale, p.o, p.d, ra, L.t_min, b, cand, st, active);   // every lane: see scan_tile
+            // every lane of a wavefront that has a ray for this tile: see scan_tile
+            if (!box_f4 || t >= 64u) scan_tile<true, true>(tile, count, (int)first, T, L.scan_scale, p.o, p.d, ra, L.t_min, b, cand, st, active);
+            else if ((mine_need >> t) & 1ull) scan_tile_stream(tile, count, (int)first, rterms, bt, p.o, p.d, ra, L.t_min, b, cand, st, active, ((lane_tiles >> t) & 1ull) != 0ull);
         }
         if (active) {
             nseg++;
