@@ -78,7 +78,7 @@ typedef struct RtLaunch {
 // A block of 32 spheres reached by at most this many lanes of a wavefront is scanned lanes-over-spheres, one reaching ray at
 // a time (scan_tile); beyond it the 64 rays scan the block's spheres side by side.
 #ifndef RT_SPARSE_MAX
-#define RT_SPARSE_MAX 8u
+#define RT_SPARSE_MAX 16u
 #endif
 // ... and a streamed tile reached by at most this many lanes has the boxes of its blocks tested lanes-over-blocks
 #ifndef RT_SPARSE_TILE_MAX

@@ -357,35 +357,43 @@ RT_DEV void filter_step(const RayTerms& r, const float4* p, uint32_t& miss) {
 
 // A block of 32 spheres that few lanes reach (with 64 independent bounce rays most reached blocks are reached by one or
 // two) is scanned the other way round.  Lane j holds sphere (j & 31) of the block -- one 16-byte LDS read per lane
-// instead of 32 broadcast reads -- and the reaching rays (`reached`: their lanes) are taken one at a time, their eight
-// filter terms read out of their lane into scalar registers: the same nine operations on the same numbers as
-// filter_step, so the same keys bit for bit, for 32 spheres at once.  Some 25 instructions per reaching ray instead of
-// 300 per block.  Called by the whole wavefront; returns the lane's mask as filter_step builds it (all ones for a
-// lane that does not reach the block).
+// instead of 32 broadcast reads -- and the reaching rays (`reached`: their lanes) are taken two at a time, one per half
+// of the wavefront, each lane fetching its ray's eight filter terms from that ray's lane: the same nine operations on
+// the same numbers as filter_step, so the same keys bit for bit, for 32 spheres at once.  Some 15 instructions per
+// reaching ray instead of 300 per block.  Called by the whole wavefront (every lane enabled); returns the lane's mask as filter_step builds it
+// (all ones for a lane that does not reach the block).
 template <bool HALF>
 RT_DEV uint32_t sparse_block(const RayTerms& r, const float4* geo_blk, unsigned long long reached) {
-    const float4 sp = geo_blk[threadIdx.x & 31u];
+    const uint32_t lane = threadIdx.x & 63u;
+    const float4 sp = geo_blk[lane & 31u];
     uint32_t miss = 0xffffffffu;
     unsigned long long todo = reached;
     while (todo != 0ull) {
-        const int l = __ffsll((long long)todo) - 1;
+        // two rays per step: lanes 0..31 test the block's spheres for the first, lanes 32..63 for the second (the same
+        // ray twice when only one is left); each lane fetches its ray's terms from that ray's lane (ds_bpermute:
+        // the LDS crossbar, no memory access)
+        const int l1 = __ffsll((long long)todo) - 1;
         todo &= todo - 1ull;
-        const float wx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r.w.x), l));
-        const float wy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r.w.y), l));
-        const float wz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r.w.z), l));
-        const float k0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r.k0), l));
-        const float ux = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r.uf.x), l));
-        const float uy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r.uf.y), l));
-        const float uz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r.uf.z), l));
-        const float e0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r.e), l));
+        int l2 = l1;
+        if (todo != 0ull) { l2 = __ffsll((long long)todo) - 1; todo &= todo - 1ull; }
+        const int src = (lane < 32u ? l1 : l2) << 2;
+        const float wx = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(r.w.x)));
+        const float wy = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(r.w.y)));
+        const float wz = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(r.w.z)));
+        const float k0 = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(r.k0)));
+        const float ux = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(r.uf.x)));
+        const float uy = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(r.uf.y)));
+        const float uz = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(r.uf.z)));
+        const float e0 = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(r.e)));
         const float t = fmaf(wz, sp.z, fmaf(wy, sp.y, fmaf(wx, sp.x, k0)));
         float g = fmaf(uz, sp.z, fmaf(uy, sp.y, fmaf(ux, sp.x, e0)));
         if (HALF) g = __builtin_amdgcn_fmed3f(g, 0.0f, 1.0f);
         const float key = fmaf(g, g, t) + sp.w;
-        // bit j of the ballot: sphere j of the block is a candidate (sign bit of its key clear); the masks of
-        // decode_block count the other way: bit j set = sphere 31 - j cannot be hit
-        const uint32_t cand32 = (uint32_t)__ballot(__float_as_int(key) >= 0);
-        if ((threadIdx.x & 63u) == (uint32_t)l) miss = ~__builtin_bitreverse32(cand32);
+        // bit j of a half of the ballot: sphere j of the block is a candidate for that half's ray (sign bit of its key
+        // clear); the masks of decode_block count the other way: bit j set = sphere 31 - j cannot be hit
+        const unsigned long long cand = __ballot(__float_as_int(key) >= 0);
+        if (lane == (uint32_t)l1) miss = ~__builtin_bitreverse32((uint32_t)cand);
+        if (lane == (uint32_t)l2) miss = ~__builtin_bitreverse32((uint32_t)(cand >> 32));
     }
     return miss;
 }
