@@ -53,7 +53,17 @@ typedef struct RtLaunch {
 #endif
 
 // spheres per unrolled scan step (8 measured best: 4 is 3 % slower, 16 costs a wave of occupancy and 2 %)
+#ifndef RT_SCAN_UNROLL
 #define RT_SCAN_UNROLL 8u
+#endif
+// ... and in the builds with block boxes, where the dense scan is the lesser part and registers are short
+#ifndef RT_SCAN_UNROLL_BOXES
+#define RT_SCAN_UNROLL_BOXES 4u
+#endif
+// ... and in the camera-ray scan
+#ifndef RT_SCAN_UNROLL_PRIMARY
+#define RT_SCAN_UNROLL_PRIMARY 4u
+#endif
 // sphere lists are padded to a multiple of this (the scans end with a step of 4 and a step of 2 spheres)
 #define RT_SCAN_PAD 2u
 // Spheres staged in LDS at a time: 1024 x 32 B = 32 KiB.  Scenes up to this size are staged once per
@@ -83,6 +93,10 @@ typedef struct RtLaunch {
 // ... and a streamed tile reached by at most this many lanes has the boxes of its blocks tested lanes-over-blocks
 #ifndef RT_SPARSE_TILE_MAX
 #define RT_SPARSE_TILE_MAX 12u
+#endif
+// waves per SIMD the streaming camera-ray-batch kernels are built for
+#ifndef RT_STREAM_WAVES
+#define RT_STREAM_WAVES 5
 #endif
 #define RT_Q_CAND_CAP 8u
 #define RT_Q_WORDS 8u

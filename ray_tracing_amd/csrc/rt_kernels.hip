@@ -505,8 +505,11 @@ RT_DEV void scan_tile(const Tile& tile, uint32_t count, int base, V3 T, float si
             }
         }
         uint32_t miss = 0u;                                            // bit j set: sphere blk + (31-j) cannot be hit
+        // (BOXES builds: four spheres per step -- the eight float4 of a longer step in flight cost 16 registers that the
+        // loop's other state needs, and most blocks go through sparse_block anyway)
+        constexpr uint32_t STEP = BOXES ? RT_SCAN_UNROLL_BOXES : RT_SCAN_UNROLL;
 #pragma unroll
-        for (uint32_t i = 0; i < 32u; i += RT_SCAN_UNROLL) filter_step<HALF, RT_SCAN_UNROLL>(r, tile.geo + blk + i, miss);
+        for (uint32_t i = 0; i < 32u; i += STEP) filter_step<HALF, STEP>(r, tile.geo + blk + i, miss);
         if (BOXES && !reach) miss = 0xffffffffu;                       // nothing of this block for a lane that does not reach it
         st.lap(9);
         decode_block<false>(tile, base, blk, 32u, miss, nullptr, o, d, a, t_min, b, c, st);
@@ -514,8 +517,9 @@ RT_DEV void scan_tile(const Tile& tile, uint32_t count, int base, V3 T, float si
     if (blk < count) {                                                 // the last 2 .. 30 spheres (count is even)
         const uint32_t k = count - blk;
         uint32_t miss = 0u, i = 0u;
-        for (; i + RT_SCAN_UNROLL <= k; i += RT_SCAN_UNROLL) filter_step<HALF, RT_SCAN_UNROLL>(r, tile.geo + blk + i, miss);
-        if (k & 4u) { filter_step<HALF, 4u>(r, tile.geo + blk + i, miss); i += 4u; }
+        constexpr uint32_t STEP = BOXES ? RT_SCAN_UNROLL_BOXES : RT_SCAN_UNROLL;
+        for (; i + STEP <= k; i += STEP) filter_step<HALF, STEP>(r, tile.geo + blk + i, miss);
+        if (STEP > 4u && (k & 4u)) { filter_step<HALF, 4u>(r, tile.geo + blk + i, miss); i += 4u; }
         if (k & 2u) filter_step<HALF, 2u>(r, tile.geo + blk + i, miss);
         if (BOXES && !act) miss = 0xffffffffu;
         st.lap(9);
@@ -539,7 +543,10 @@ RT_DEV void scan_tile_stream(const Tile& tile, uint32_t count, int base, const R
     const unsigned long long tr = __ballot(tile_reach);
     uint32_t mine = 0u;                                               // bit j: this lane's ray reaches block j of the tile
     uint32_t anybody = 0u;                                            // ... some lane's does (wave-uniform)
-    if ((uint32_t)__popcll(tr) <= RT_SPARSE_TILE_MAX) {
+    if (!tile.box) {                                                  // no boxes: every block, every lane with a ray
+        mine = tile_reach ? (1u << n_full) - 1u : 0u;
+        anybody = tr != 0ull ? (1u << n_full) - 1u : 0u;
+    } else if ((uint32_t)__popcll(tr) <= RT_SPARSE_TILE_MAX) {
         const uint32_t jb = lane & 15u;
         const float4 lo = tile.box[2u * jb], hi = tile.box[2u * jb + 1u];
         unsigned long long todo = tr;
@@ -597,7 +604,7 @@ RT_DEV void scan_tile_stream(const Tile& tile, uint32_t count, int base, const R
         } else {
             miss = 0u;
 #pragma unroll
-            for (uint32_t i = 0; i < 32u; i += RT_SCAN_UNROLL) filter_step<true, RT_SCAN_UNROLL>(r, tile.geo + blk + i, miss);
+            for (uint32_t i = 0; i < 32u; i += RT_SCAN_UNROLL_BOXES) filter_step<true, RT_SCAN_UNROLL_BOXES>(r, tile.geo + blk + i, miss);
             if (!reach) miss = 0xffffffffu;
         }
         st.lap(9);
@@ -606,8 +613,8 @@ RT_DEV void scan_tile_stream(const Tile& tile, uint32_t count, int base, const R
     if (count & 31u) {                                                 // the list's last 2 .. 30 spheres: no box, every lane with a ray
         const uint32_t blk = 32u * n_full, k = count - blk;
         uint32_t miss = 0u, i = 0u;
-        for (; i + RT_SCAN_UNROLL <= k; i += RT_SCAN_UNROLL) filter_step<true, RT_SCAN_UNROLL>(r, tile.geo + blk + i, miss);
-        if (k & 4u) { filter_step<true, 4u>(r, tile.geo + blk + i, miss); i += 4u; }
+        for (; i + RT_SCAN_UNROLL_BOXES <= k; i += RT_SCAN_UNROLL_BOXES) filter_step<true, RT_SCAN_UNROLL_BOXES>(r, tile.geo + blk + i, miss);
+        if (RT_SCAN_UNROLL_BOXES > 4u && (k & 4u)) { filter_step<true, 4u>(r, tile.geo + blk + i, miss); i += 4u; }
         if (k & 2u) filter_step<true, 2u>(r, tile.geo + blk + i, miss);
         if (!act) miss = 0xffffffffu;
         st.lap(9);
@@ -661,19 +668,22 @@ RT_DEV void scan_primary(const float4* geo0, const uint16_t* map, const Tile& ti
                          float fx, float fy, V3 o, V3 d, float a, float t_min, Best& b, Cand& c, Stats& st) {
     st.wave(0);
     const float iLs = filter_inv_len(a);
+    // (four spheres per step: a unit's list has a handful of entries, and the eight float4 of a longer step in flight
+    // cost the caller -- which holds its lanes' bounce paths meanwhile -- 16 registers)
+    constexpr uint32_t STEP = RT_SCAN_UNROLL_PRIMARY;
     uint32_t blk = 0u;
     for (; blk + 32u <= count; blk += 32u) {
         uint32_t miss = 0u;
 #pragma unroll
-        for (uint32_t i = 0; i < 32u; i += RT_SCAN_UNROLL) primary_step<RT_SCAN_UNROLL>(fx, fy, iLs, geo0 + blk + i, miss);
+        for (uint32_t i = 0; i < 32u; i += STEP) primary_step<STEP>(fx, fy, iLs, geo0 + blk + i, miss);
         st.lap(15);
         decode_block<true>(tile, base, blk, 32u, miss, map, o, d, a, t_min, b, c, st);
     }
     if (blk < count) {
         const uint32_t k = count - blk;
         uint32_t miss = 0u, i = 0u;
-        for (; i + RT_SCAN_UNROLL <= k; i += RT_SCAN_UNROLL) primary_step<RT_SCAN_UNROLL>(fx, fy, iLs, geo0 + blk + i, miss);
-        if (k & 4u) { primary_step<4u>(fx, fy, iLs, geo0 + blk + i, miss); i += 4u; }
+        for (; i + STEP <= k; i += STEP) primary_step<STEP>(fx, fy, iLs, geo0 + blk + i, miss);
+        if (STEP > 4u && (k & 4u)) { primary_step<4u>(fx, fy, iLs, geo0 + blk + i, miss); i += 4u; }
         if (k & 2u) primary_step<2u>(fx, fy, iLs, geo0 + blk + i, miss);
         st.lap(15);
         decode_block<true>(tile, base, blk, k, miss, map, o, d, a, t_min, b, c, st);
@@ -2085,8 +2095,10 @@ RT_DEV void render_queue_stream_body(const Scene& sc, uint32_t* __restrict__ rgb
             __syncthreads();
             const Tile tile = {geo, sc.exact + first, box_f4 ? box : nullptr, orig_of(L, sc.mat), box_f4 ? box + (box_f4 - 2u) : nullptr};   // exact-test data from global memory
             // every lane of a wavefront that has a ray for this tile: see scan_tile
-            if (!box_f4 || t >= 64u) scan_tile<true, true>(tile, count, (int)first, T, L.scan_scale, p.o, p.d, ra, L.t_min, b, cand, st, active);
-            else if ((mine_need >> t) & 1ull) scan_tile_stream(tile, count, (int)first, rterms, bt, p.o, p.d, ra, L.t_min, b, cand, st, active, ((lane_tiles >> t) & 1ull) != 0ull);
+            // (no boxes, or a tile beyond the 64 that were voted on: every lane with a ray counts as reaching the tile)
+            const bool voted = box_f4 && t < 64u;
+            if (!voted || ((mine_need >> t) & 1ull))
+                scan_tile_stream(tile, count, (int)first, rterms, bt, p.o, p.d, ra, L.t_min, b, cand, st, active, voted ? ((lane_tiles >> t) & 1ull) != 0ull : active);
         }
         if (active) {
             nseg++;
@@ -2154,7 +2166,7 @@ rt_render_queue_boxes(const float4* geom, const float4* exact, const float4* sha
     render_queue_body<false, true>(sc, rgba, linear, segments, work, fold, camterms, cam, L);
 }
 
-extern "C" __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(5)))
+extern "C" __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(RT_STREAM_WAVES)))
 rt_render_queue_stream(const float4* geom, const float4* exact, const float4* shade, const uint32_t* mat, uint32_t* rgba,
                        float4* linear, unsigned long long* segments, uint32_t* work, float4* fold, const float4* camterms,
                        RtCamera cam, RtLaunch L) {
@@ -2217,7 +2229,7 @@ rt_render_pool_fold(const float4* geom, const float4* exact, const float4* shade
     render_pool_body<true, true, true>(sc, rgba, linear, segments, work, fold, camterms, cam, L);
 }
 
-extern "C" __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(5)))
+extern "C" __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(RT_STREAM_WAVES)))
 rt_render_queue_stream_fold(const float4* geom, const float4* exact, const float4* shade, const uint32_t* mat, uint32_t* rgba,
                             float4* linear, unsigned long long* segments, uint32_t* work, float4* fold, const float4* camterms,
                             RtCamera cam, RtLaunch L) {
