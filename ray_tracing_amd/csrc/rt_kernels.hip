@@ -1,12 +1,17 @@
 // rt_kernels.hip -- gfx950 code object of the path tracer: the sphere list streamed from LDS (every lane
 // of a wavefront reads the same float4 per step), counter-based PCG32 streams, fp32 register
-// accumulation, gamma + RGBA8 store.  Six render kernels share the code below:
+// accumulation, gamma + RGBA8 store.  The render kernels share the code below:
 //   rt_render_queue         every sample its own work item, scene within one LDS tile (the fast path)
-//   rt_render_queue_stream  the same for longer sphere lists, streamed tile by tile
-//   rt_render_queue_fold, rt_render_queue_stream_fold   the same two, adding each pixel's samples in sample order
+//   rt_render_queue_boxes   the same with a bounding box per block of 32 spheres of a list sorted in space: a bounce
+//                           ray's scan skips the blocks no lane reaches, and scans a block few lanes reach for those
+//                           lanes only, lanes over spheres (scan_tile, sparse_block)
+//   rt_render_pool, rt_render_pool_boxes, rt_render_pool_plain   the same with the pixel units pooled per workgroup
+//   rt_render_queue_stream  the same for longer sphere lists, streamed tile by tile (scan_tile_stream)
+//   rt_render_queue_fold, rt_render_pool_fold, rt_render_queue_stream_fold   adding each pixel's samples in sample order
 //   rt_render               work items of `chunk` samples, or one lane per pixel in the reference's fold order
 //   rt_render_stream        the same for longer sphere lists
-// and rt_camera_terms runs before the first four: the camera-ray scan's four numbers per sphere for the launch's camera.
+// and rt_camera_terms runs before the camera-ray-batch kernels: the camera-ray scan's four numbers per sphere for the
+// launch's camera.
 // Built with
 //   hipcc --offload-arch=gfx950 --genco -O3 -ffp-contract=off
 // and loaded with hipModuleLoadData by rt_hip.cpp.  No MFMA: the work is divergent scalar fp32.
