@@ -713,6 +713,45 @@ def test_sorted_sphere_list_and_block_boxes_change_nothing(rt, monkeypatch):
         assert frames[0]["kernel_ms"] < 0.85 * frames[1]["kernel_ms"], (frames[0]["kernel_ms"], frames[1]["kernel_ms"])
 
 
+def test_scans_turned_round_and_large_spheres_apart_change_nothing(rt, monkeypatch):
+    """A block of 32 spheres that at most 16 lanes of a wavefront reach is scanned lanes-over-spheres, two reaching rays
+    at a time (sparse_block), a streamed tile that at most 12 lanes reach has the boxes of its blocks tested
+    lanes-over-blocks (scan_tile_stream), the workgroup votes on the tiles of a round, and the large spheres of a sorted
+    list sit behind the small ones' last block.  None of it may change a bit: the book scene at 4K (per-wavefront and
+    pooled kernel) and the 16,385-sphere grid (streamed list) give the same frame and the same segment count with the
+    default code object, with a build that scans every reached block and tests every reached tile's boxes with all 64
+    lanes (rt_kernels_x_dense.hsaco), and with the large spheres left at the head of the list (RT_EXP_BIG_FIRST, read
+    at upload) -- and the default is the fastest of the three on the book frame."""
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ray_tracing_amd", "csrc", "rt_kernels_x_dense.hsaco")
+    if not os.path.exists(path):
+        pytest.skip("dense-only code object not built (make -C ray_tracing_amd/csrc)")
+    dense = open(path, "rb").read()
+    cases = [("book", rt.scene_book1_final(1), rt.Camera.look_at(16.0 / 9.0, 3840, 20.0, (13.0, 2.0, 3.0), (0.0, 0.0, 0.0)), 100, 50, ("wave", "pool")),
+             ("grid", rt.scene_grid(2, 128), rt.Camera.look_at(16.0 / 9.0, 1920, 40.0, (0.0, 30.0, 80.0), (0.0, 0.0, 0.0)), 16, 16, ("wave",))]
+    for name, sp, cam, spp, depth, scheds in cases:
+        p = rt.DeviceGUI(samples_per_pixel=spp, max_depth=depth, seed=1, sample_chunk=1)
+        for sched in scheds:
+            frames = {}
+            for arm in ("default", "dense", "big_first"):
+                if arm == "big_first":
+                    monkeypatch.setenv("RT_EXP_BIG_FIRST", "1")
+                with rt.HipWorld(0, sp) as w:
+                    if arm == "dense":
+                        w.load_module(dense)
+                    w.debug_schedule(scheduler=sched)
+                    w.render(cam, p)                                     # (warm-up: the first launch of a context is slower)
+                    frames[arm] = w.render(cam, p, linear=True)
+                    assert "boxes" in w.last_kernel_name() or "stream" in w.last_kernel_name(), w.last_kernel_name()
+                monkeypatch.delenv("RT_EXP_BIG_FIRST", raising=False)
+            for arm in ("dense", "big_first"):
+                assert frames[arm]["rays"] == frames["default"]["rays"], (name, sched, arm)
+                assert np.array_equal(frames[arm]["linear"].view(np.uint32), frames["default"]["linear"].view(np.uint32)), (name, sched, arm)
+            if name == "book":
+                assert frames["default"]["kernel_ms"] < 0.9 * frames["dense"]["kernel_ms"], (sched, frames["default"]["kernel_ms"], frames["dense"]["kernel_ms"])
+                assert frames["default"]["kernel_ms"] < 0.98 * frames["big_first"]["kernel_ms"], (sched, frames["default"]["kernel_ms"], frames["big_first"]["kernel_ms"])
+
+
 def test_block_boxes_never_exclude_a_sphere_the_exact_test_accepts(rt):
     """The diagnostics build of the kernels (-DRT_BOXCHECK): a lane whose ray misses a block's box runs the exact test
     on the block's 32 spheres all the same and records the ray if one of them is accepted.  Nothing is recorded on the
