@@ -764,6 +764,40 @@ int rt_upload_scene(rt_ctx* c, const RtSphere* spheres, uint32_t n) {
         }
         std::sort(key.begin(), key.end());
         for (uint32_t i = 0; i < n; i++) order[i] = (uint32_t)(key[i] & 0xffffffffu);
+        // The small spheres (behind the n_big large ones in `order`) are then put in the order of a median-split tree
+        // instead: the set is cut across its longest extent into two parts of whole blocks of 32 (whole tiles of
+        // RT_Q_STREAM_TILE while it is larger than one), and so on down to single blocks.  Blocks of exactly 32
+        // consecutive spheres of a Z-order curve straddle the curve's cells and come out ragged; these are boxes cut
+        // to measure, and fewer of them are reached by a ray.
+        if (!std::getenv("RT_EXP_MORTON")) {
+            struct Cut { uint32_t first, count; };
+            std::vector<Cut> todo;
+            todo.push_back({n_big, n - n_big});
+            while (!todo.empty()) {
+                const Cut cut = todo.back();
+                todo.pop_back();
+                if (cut.count <= 32u) continue;
+                const uint32_t granule = cut.count > RT_Q_STREAM_TILE ? RT_Q_STREAM_TILE : 32u;
+                const uint32_t parts = (cut.count + granule - 1u) / granule;
+                const uint32_t left = (parts / 2u) * granule;                      // whole blocks (tiles) on the left
+                float ext_lo[3] = {INFINITY, INFINITY, INFINITY}, ext_hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+                for (uint32_t i = cut.first; i < cut.first + cut.count; i++)
+                    for (int k = 0; k < 3; k++) {
+                        const float c = spheres[order[i]].center[k];
+                        if (c < ext_lo[k]) ext_lo[k] = c;
+                        if (c > ext_hi[k]) ext_hi[k] = c;
+                    }
+                int axis = 0;
+                for (int k = 1; k < 3; k++) if (ext_hi[k] - ext_lo[k] > ext_hi[axis] - ext_lo[axis]) axis = k;
+                auto first = order.begin() + cut.first;
+                std::nth_element(first, first + left, first + cut.count, [&](uint32_t a, uint32_t b) {
+                    const float ca = spheres[a].center[axis], cb = spheres[b].center[axis];
+                    return ca < cb || (ca == cb && a < b);
+                });
+                todo.push_back({cut.first, left});
+                todo.push_back({cut.first + left, cut.count - left});
+            }
+        }
     }
     // Device slots.  A large sphere's box is reached by nearly every ray, and a block that holds one is scanned by all 64
     // lanes of nearly every wavefront -- 32 spheres for the sake of one.  So the large spheres get the end of the list to
