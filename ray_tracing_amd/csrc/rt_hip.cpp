@@ -765,7 +765,7 @@ int rt_upload_scene(rt_ctx* c, const RtSphere* spheres, uint32_t n) {
         std::sort(key.begin(), key.end());
         for (uint32_t i = 0; i < n; i++) order[i] = (uint32_t)(key[i] & 0xffffffffu);
         // The small spheres (behind the n_big large ones in `order`) are then put in the order of a median-split tree
-        // instead: the set is cut across its longest extent into two parts of whole blocks of 32 (whole tiles of
+        // instead: the set is cut across one axis into two parts of whole blocks of 32 (whole tiles of
         // RT_Q_STREAM_TILE while it is larger than one), and so on down to single blocks.  Blocks of exactly 32
         // consecutive spheres of a Z-order curve straddle the curve's cells and come out ragged; these are boxes cut
         // to measure, and fewer of them are reached by a ray.
@@ -780,16 +780,30 @@ int rt_upload_scene(rt_ctx* c, const RtSphere* spheres, uint32_t n) {
                 const uint32_t granule = cut.count > RT_Q_STREAM_TILE ? RT_Q_STREAM_TILE : 32u;
                 const uint32_t parts = (cut.count + granule - 1u) / granule;
                 const uint32_t left = (parts / 2u) * granule;                      // whole blocks (tiles) on the left
-                float ext_lo[3] = {INFINITY, INFINITY, INFINITY}, ext_hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-                for (uint32_t i = cut.first; i < cut.first + cut.count; i++)
-                    for (int k = 0; k < 3; k++) {
-                        const float c = spheres[order[i]].center[k];
-                        if (c < ext_lo[k]) ext_lo[k] = c;
-                        if (c > ext_hi[k]) ext_hi[k] = c;
-                    }
-                int axis = 0;
-                for (int k = 1; k < 3; k++) if (ext_hi[k] - ext_lo[k] > ext_hi[axis] - ext_lo[axis]) axis = k;
+                // the cut: of the three axes the one whose two parts' boxes (spheres with their radii) have the smallest
+                // total surface
                 auto first = order.begin() + cut.first;
+                auto surface = [&](uint32_t from, uint32_t to) {
+                    double lo3[3] = {INFINITY, INFINITY, INFINITY}, hi3[3] = {-INFINITY, -INFINITY, -INFINITY};
+                    for (uint32_t i = from; i < to; i++)
+                        for (int k = 0; k < 3; k++) {
+                            const double c = spheres[order[i]].center[k], r = std::fabs((double)spheres[order[i]].radius);
+                            lo3[k] = std::min(lo3[k], c - r);
+                            hi3[k] = std::max(hi3[k], c + r);
+                        }
+                    const double e[3] = {hi3[0] - lo3[0], hi3[1] - lo3[1], hi3[2] - lo3[2]};
+                    return e[0] * e[1] + e[1] * e[2] + e[2] * e[0];
+                };
+                int axis = 0;
+                double best = INFINITY;
+                for (int k = 0; k < 3; k++) {
+                    std::nth_element(first, first + left, first + cut.count, [&](uint32_t a, uint32_t b) {
+                        const float ca = spheres[a].center[k], cb = spheres[b].center[k];
+                        return ca < cb || (ca == cb && a < b);
+                    });
+                    const double area = surface(cut.first, cut.first + left) + surface(cut.first + left, cut.first + cut.count);
+                    if (area < best) { best = area; axis = k; }
+                }
                 std::nth_element(first, first + left, first + cut.count, [&](uint32_t a, uint32_t b) {
                     const float ca = spheres[a].center[axis], cb = spheres[b].center[axis];
                     return ca < cb || (ca == cb && a < b);
