@@ -176,7 +176,7 @@ int rt_debug_fold_workspace_limit(rt_ctx *ctx, uint64_t bytes);
  * both off every path segment is tested against every sphere of the list, as in the reference; the image is the same
  * bit for bit either way.
  *   unit_lists  != 0 (default): the camera rays of a pixel unit scan the unit's short list of spheres, made once per unit
- *   block_boxes != 0 (default): scenes of 128 spheres and more are kept sorted in space, and a bounce ray's scan skips
+ *   block_boxes != 0 (default): scenes of 32 spheres and more are kept sorted in space, and a bounce ray's scan skips
  *                               a block of 32 spheres whose bounding box no lane's ray reaches
  * Takes effect at the next launch.  No counterpart in the reference. */
 int rt_debug_cull(rt_ctx *ctx, int unit_lists, int block_boxes);

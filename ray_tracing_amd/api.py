@@ -322,7 +322,7 @@ class HipWorld:
     def debug_cull(self, unit_lists=True, block_boxes=True):
         """Measurement aid: with both off every path segment is tested against every sphere of the list, as in the
         reference's loop (the image does not change).  unit_lists: camera rays scan their pixel unit's short sphere list;
-        block_boxes: bounce rays skip blocks of 32 spheres whose bounding box they miss (scenes of 128 spheres and more)."""
+        block_boxes: bounce rays skip blocks of 32 spheres whose bounding box they miss (scenes of 32 spheres and more)."""
         self._check(self._lib.rt_debug_cull(self._ctx, int(bool(unit_lists)), int(bool(block_boxes))))
 
     def device_info(self):

@@ -2161,7 +2161,7 @@ rt_render_queue(const float4* geom, const float4* exact, const float4* shade, co
 }
 
 // rt_render_queue built with the blocks' bounding boxes in the bounce scan, for scenes whose sphere list the launcher
-// sorted in space (128 spheres and more): on the 485-sphere book scene two thirds of the blocks are not scanned.
+// sorted in space (32 spheres and more): on the 485-sphere book scene a bounce trip reaches 5 of the 16 blocks.
 extern "C" __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6)))
 rt_render_queue_boxes(const float4* geom, const float4* exact, const float4* shade, const uint32_t* mat, uint32_t* rgba,
                       float4* linear, unsigned long long* segments, uint32_t* work, float4* fold, const float4* camterms,

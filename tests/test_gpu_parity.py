@@ -20,11 +20,11 @@ def rt():
 
 # The pooled kernel has a build without the pixel units' sphere lists, run where a launch has none (fewer than 16
 # spheres, or no room in LDS beside 64-pixel units), and one with the blocks' bounding boxes in its bounce scan (scenes
-# of 128 spheres and more): which of them runs is not what most tests here are about.
+# of 32 spheres and more): which of them runs is not what most tests here are about.
 POOLED = ("rt_render_pool", "rt_render_pool_plain", "rt_render_pool_boxes")
 
 
-# ... and the per-wavefront kernel a build with the blocks' bounding boxes in its bounce scan, run on scenes of 128
+# ... and the per-wavefront kernel a build with the blocks' bounding boxes in its bounce scan, run on scenes of 32
 # spheres and more (the launcher sorts those in space).
 WAVE = ("rt_render_queue", "rt_render_queue_boxes")
 
@@ -690,7 +690,7 @@ def test_every_sphere_tested_or_culled_is_the_same_frame(rt, hip):
 
 
 def test_sorted_sphere_list_and_block_boxes_change_nothing(rt, monkeypatch):
-    """Scenes of 128 spheres and more are sorted in space at upload and the bounce scan skips blocks of 32 spheres
+    """Scenes of 32 spheres and more are sorted in space at upload and the bounce scan skips blocks of 32 spheres
     whose bounding box no lane's ray reaches (scan_tile).  The full-size frames -- book scene 4K at 500 spp (twelve
     thousand million segments, among them some thirty whose two nearest spheres report the very same root: ties go to
     the caller's earlier sphere, whatever the device order) and the 16,385-sphere grid -- are the same bit for bit,

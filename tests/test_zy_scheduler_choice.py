@@ -36,8 +36,8 @@ def test_library_picks_the_faster_scheduler_across_launch_sizes():
                     ms[sched], kernel[sched], rays[sched] = best, hip.last_kernel_name(), r
                     sums[sched] = int(buf[: n * tiles.TILE_ROWS].to(torch.int64).sum().item())
                 hip.debug_schedule()
-                assert kernel["wave"] == ("rt_render_queue_boxes" if name == "book" else "rt_render_queue")      # (boxes: scenes of 128 spheres and more)
-                assert kernel["pool"] == ("rt_render_pool_boxes" if name == "book" else "rt_render_pool")
+                assert kernel["wave"] == "rt_render_queue_boxes"      # (boxes: scenes of 32 spheres and more)
+                assert kernel["pool"] == "rt_render_pool_boxes"
                 assert rays["wave"] == rays["pool"] == rays["auto"] and sums["wave"] == sums["pool"] == sums["auto"]
                 fastest = min(ms["wave"], ms["pool"])
                 report.append(f"{name} 1/{world}: wave {ms['wave']:.1f} ms, pool {ms['pool']:.1f} ms, library ({kernel['auto']}) {ms['auto']:.1f} ms")
