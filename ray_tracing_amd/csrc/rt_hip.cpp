@@ -267,12 +267,18 @@ RtLaunch make_launch(const rt_ctx* c, const RtCamera* cam, const RtParams* p, ui
             while (L.unit_w * L.unit_h < 64u) {
                 const uint64_t items = (uint64_t)L.unit_w * L.unit_h * L.n_chunks, samples = (uint64_t)L.unit_w * L.unit_h * spp;
                 uint32_t w = L.unit_w, h = L.unit_h;
-                if (w < 16u || !height_ok(2u * h)) w *= 2u; else h *= 2u;
+                // (8 wide, then two rows, then 16 wide, then more rows: the bounce rays of a compact unit start close
+                // together and reach fewer blocks of the sphere list than those of a 16x1 strip -- 16,385-sphere frame
+                // 122 -> 115 ms with 8x2 against 8x1 units, book 4K frame 313 -> 310 ms against 16x1)
+                if (w < 8u) w *= 2u;
+                else if (h < 2u && height_ok(2u)) h = 2u;
+                else if (w < 16u || !height_ok(2u * h)) w *= 2u;
+                else h *= 2u;
                 // (a unit is written as one row segment per row and taken with one atomic add on the work counter, which
                 // the memory side executes: the HBM write counter shows the frame once plus 32 bytes per unit, at any unit
                 // shape.  A unit that is large enough still widens to 16 pixels, a whole 64-byte line per store and half
                 // the atomics of 8; measured equal in time at every launch size.)
-                if (items >= 512u && ((samples >= 2048u && L.unit_w >= 16u) || n_units_with(w, h) < min_units)) break;
+                if (items >= 512u && ((samples >= 2048u && L.unit_w * L.unit_h >= 16u) || n_units_with(w, h) < min_units)) break;
                 L.unit_w = w; L.unit_h = h;
             }
         };
@@ -294,7 +300,9 @@ RtLaunch make_launch(const rt_ctx* c, const RtCamera* cam, const RtParams* p, ui
                                c->dbg_scheduler != RT_SCHED_WAVE;
         grow(0u);
         if (pool_able && (small_launch || c->dbg_scheduler == RT_SCHED_POOL)) L.pool_slots = 1u;
-        else grow(80u * resident);
+        // (a streamed list: a round through the tiles costs the same whatever the units, and 8x2 units at 25 per wavefront
+        // beat 8x1 at 50 -- 16,385-sphere frame at 64 spp 122 -> 115 ms)
+        else grow((c->n_padded > RT_TILE_SPHERES ? 20u : 80u) * resident);
         // Sphere lists streamed through LDS: a pass over the whole list takes the better part of a millisecond, a unit
         // of 512 samples some 25 of them, and the wavefronts of a launch finish a unit apart.  With fewer than 10 such
         // units per resident wavefront (20 per compute unit on that kernel) the units are halved once: measured on the
