@@ -262,16 +262,19 @@ RtLaunch make_launch(const rt_ctx* c, const RtCamera* cam, const RtParams* p, ui
         auto n_units_with = [&](uint32_t w, uint32_t h) {
             return (uint64_t)((cam->image_width + w - 1u) / w) * ((rows_local + h - 1u) / h);
         };
+        const bool compact = c->n_padded > RT_TILE_SPHERES;
         auto grow = [&](uint64_t min_units) {
             L.unit_w = 4u; L.unit_h = 1u;
             while (L.unit_w * L.unit_h < 64u) {
                 const uint64_t items = (uint64_t)L.unit_w * L.unit_h * L.n_chunks, samples = (uint64_t)L.unit_w * L.unit_h * spp;
                 uint32_t w = L.unit_w, h = L.unit_h;
-                // (8 wide, then two rows, then 16 wide, then more rows: the bounce rays of a compact unit start close
-                // together and reach fewer blocks of the sphere list than those of a 16x1 strip -- 16,385-sphere frame
-                // 122 -> 115 ms with 8x2 against 8x1 units, book 4K frame 313 -> 310 ms against 16x1)
+                // Streamed lists: 8 wide, then two rows, then 16 wide -- the bounce rays of a compact unit start close
+                // together and reach fewer tiles and blocks (16,385-sphere frame 122 -> 115 ms with 8x2 against 8x1 units).
+                // Otherwise 16 wide first: a unit's row is then a whole 64-byte line (8x2 units measured 1 % faster on the
+                // book 4K frame and 0.4 % on the 8K mirror hall, but there the half lines of neighbouring units, written
+                // at different times from different XCDs, showed as 170 MB more HBM writes per frame).
                 if (w < 8u) w *= 2u;
-                else if (h < 2u && height_ok(2u)) h = 2u;
+                else if (compact && h < 2u && height_ok(2u)) h = 2u;
                 else if (w < 16u || !height_ok(2u * h)) w *= 2u;
                 else h *= 2u;
                 // (a unit is written as one row segment per row and taken with one atomic add on the work counter, which
