@@ -514,6 +514,19 @@ def test_fold_order_runs_on_the_batch_kernels_and_on_the_pixel_kernel(oracle, rt
     hip.debug_schedule()
 
 
+def test_list_of_more_than_64_tiles(oracle, rt, hip):
+    """40,001 spheres: 79 tiles of 512.  The workgroup's vote covers the first 64 tiles of a round; the tiles beyond
+    are staged for everybody and every lane with a ray tests the boxes of their blocks.  Chunked and fold order against
+    the checker, bit for bit (a small frame: the checker tests every sphere for every segment)."""
+    sp = rt.scene_grid(5, 200)
+    assert len(sp) > 64 * 512
+    cam = rt.Camera.look_at(16.0 / 9.0, 80, 40.0, (0.0, 40.0, 110.0), (0.0, 0.0, 0.0))
+    check_render(oracle, hip, cam, sp, rt.DeviceGUI(samples_per_pixel=4, max_depth=8, seed=4, sample_chunk=1))
+    assert hip.last_kernel_name() == "rt_render_queue_stream"
+    check_render(oracle, hip, cam, sp, rt.DeviceGUI(samples_per_pixel=3, max_depth=8, seed=4))
+    assert hip.last_kernel_name() == "rt_render_queue_stream_fold"
+
+
 def test_tiny_negative_run_sums(oracle, rt, hip):
     """Negative albedos give run sums just below zero, where the fixed-point conversion has to carry
     (floor -1, fraction rounding to 1): kernel and checker agree bit for bit in every accumulation mode."""
