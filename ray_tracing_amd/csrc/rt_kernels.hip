@@ -540,6 +540,10 @@ RT_DEV void scan_tile(const Tile& tile, uint32_t count, int base, V3 T, float si
 // the tile, lane j holds the box of block (j & 15) and the reaching rays are taken one at a time, their nine slab
 // terms in scalar registers -- 30 instructions per reaching ray instead of 25 per block for all 64 lanes; then only
 // the blocks somebody reaches are visited at all.
+// tile.exa is the WHOLE list's exact-test data and the candidates are listed by their index in the list (base + index
+// in the tile): the lists are not drained here but by the caller, once per path segment after the last tile (and by
+// decode_block where one fills up) -- an exact-test round waits for global memory, and a wavefront has rays for eight
+// tiles of a round but only two or three candidates per ray in all.
 RT_DEV void scan_tile_stream(const Tile& tile, uint32_t count, int base, const RayTerms& r, const BoxTerms& bt, V3 o, V3 d, float a,
                              float t_min, Best& b, Cand& c, Stats& st, bool act, bool tile_reach) {
     st.wave(1);
@@ -585,11 +589,11 @@ RT_DEV void scan_tile_stream(const Tile& tile, uint32_t count, int base, const R
         for (uint32_t j = 0u; j < n_full; j++)
             if (!((mine >> j) & 1u))
                 for (uint32_t i = 0; i < 32u; i++) {
-                    const float4 e = tile.exa[32u * j + i];
+                    const float4 e = tile.exa[(uint32_t)base + 32u * j + i];
                     float hh, nn, dd;
                     sphere_terms(e.x, e.y, e.z, e.w, o, d, a, hh, nn, dd);
                     Best tmp; tmp.t = INFINITY; tmp.idx = -1;
-                    accept_exact(hh, nn, dd, a, t_min, (int)(32u * j + i), tile.orig, tmp);
+                    accept_exact(hh, nn, dd, a, t_min, base + (int)(32u * j + i), tile.orig, tmp);
                     if (tmp.idx >= 0 && rt_dbg_ptr) {
                         float* w = reinterpret_cast<float*>(rt_dbg_ptr + 1);
                         w[0] = o.x; w[1] = o.y; w[2] = o.z; w[3] = d.x; w[4] = d.y; w[5] = d.z;
@@ -613,7 +617,7 @@ RT_DEV void scan_tile_stream(const Tile& tile, uint32_t count, int base, const R
             if (!reach) miss = 0xffffffffu;
         }
         st.lap(9);
-        decode_block<false>(tile, base, blk, 32u, miss, nullptr, o, d, a, t_min, b, c, st);
+        decode_block<false>(tile, 0, (uint32_t)base + blk, 32u, miss, nullptr, o, d, a, t_min, b, c, st);
     }
     if (count & 31u) {                                                 // the list's last 2 .. 30 spheres: no box, every lane with a ray
         const uint32_t blk = 32u * n_full, k = count - blk;
@@ -623,10 +627,8 @@ RT_DEV void scan_tile_stream(const Tile& tile, uint32_t count, int base, const R
         if (k & 2u) filter_step<true, 2u>(r, tile.geo + blk + i, miss);
         if (!act) miss = 0xffffffffu;
         st.lap(9);
-        decode_block<false>(tile, base, blk, k, miss, nullptr, o, d, a, t_min, b, c, st);
+        decode_block<false>(tile, 0, (uint32_t)base + blk, k, miss, nullptr, o, d, a, t_min, b, c, st);
     }
-    drain(tile, base, c, o, d, a, t_min, b, st);
-    st.lap(11);
 }
 
 // The scan for camera rays.  They all leave from the camera centre o, and their directions are an affine function
@@ -2098,13 +2100,14 @@ RT_DEV void render_queue_stream_body(const Scene& sc, uint32_t* __restrict__ rgb
                 else if (first / 16u + i < 2u * L.scan_blocks) box[i] = sc.geom[L.n_padded + first / 16u + i];
             }
             __syncthreads();
-            const Tile tile = {geo, sc.exact + first, box_f4 ? box : nullptr, orig_of(L, sc.mat), box_f4 ? box + (box_f4 - 2u) : nullptr};   // exact-test data from global memory
+            const Tile tile = {geo, sc.exact, box_f4 ? box : nullptr, orig_of(L, sc.mat), box_f4 ? box + (box_f4 - 2u) : nullptr};   // exact-test data: the whole list's, in global memory
             // every lane of a wavefront that has a ray for this tile: see scan_tile
             // (no boxes, or a tile beyond the 64 that were voted on: every lane with a ray counts as reaching the tile)
             const bool voted = box_f4 && t < 64u;
             if (!voted || ((mine_need >> t) & 1ull))
                 scan_tile_stream(tile, count, (int)first, rterms, bt, p.o, p.d, ra, L.t_min, b, cand, st, active, voted ? ((lane_tiles >> t) & 1ull) != 0ull : active);
         }
+        drain(whole, 0, cand, p.o, p.d, ra, L.t_min, b, st);     // the segment's candidates, from all its tiles
         if (active) {
             nseg++;
             V3 color;
