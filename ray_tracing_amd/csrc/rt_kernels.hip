@@ -535,8 +535,7 @@ RT_DEV void scan_tile(const Tile& tile, uint32_t count, int base, V3 T, float si
 }
 
 // scan_tile for one staged tile of a streamed list (whole blocks, plus a short last step behind them where the list
-// ends), for the lanes whose ray reaches the tile's box (`tile_reach`; the caller has tested it and calls only if some
-// lane does).  The blocks' boxes are tested the way sparse_block scans: where at most RT_SPARSE_TILE_MAX lanes reach
+// ends), for the lanes whose ray reaches the tile's box (the caller calls only if some lane's does).  The blocks' boxes are tested the way sparse_block scans: where at most RT_SPARSE_TILE_MAX lanes reach
 // the tile, lane j holds the box of block (j & 15) and the reaching rays are taken one at a time, their nine slab
 // terms in scalar registers -- 30 instructions per reaching ray instead of 25 per block for all 64 lanes; then only
 // the blocks somebody reaches are visited at all.
@@ -545,8 +544,16 @@ RT_DEV void scan_tile(const Tile& tile, uint32_t count, int base, V3 T, float si
 // decode_block where one fills up) -- an exact-test round waits for global memory, and a wavefront has rays for eight
 // tiles of a round but only two or three candidates per ray in all.
 RT_DEV void scan_tile_stream(const Tile& tile, uint32_t count, int base, const RayTerms& r, const BoxTerms& bt, V3 o, V3 d, float a,
-                             float t_min, Best& b, Cand& c, Stats& st, bool act, bool tile_reach) {
+                             float t_min, Best& b, Cand& c, Stats& st, bool act) {
     st.wave(1);
+    // (the lane's own answer for this tile once more, from the staged box: a bit per tile kept from the vote would cost
+    // the round two registers)
+    bool tile_reach = act;
+    if (tile.tbox) {
+        float tn, tf;
+        box_span(bt, tile.tbox[0], tile.tbox[1], tn, tf);
+        tile_reach = act && !(tf < tn);
+    }
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t n_full = count >> 5;                               // <= 16: RT_Q_STREAM_TILE / 32
     const unsigned long long tr = __ballot(tile_reach);
@@ -2062,7 +2069,7 @@ RT_DEV void render_queue_stream_body(const Scene& sc, uint32_t* __restrict__ rgb
         // beyond are staged as before).  The two vote words take turns: the one not in use is cleared after the
         // barrier, a round before it is voted in again.
         unsigned long long needed = ~0ull;
-        unsigned long long lane_tiles = 0ull, mine_need = 0ull;     // tiles this lane's ray reaches; tiles some lane of this wavefront reaches
+        unsigned long long mine_need = 0ull;                        // tiles some lane of this wavefront reaches
         const V3 op = vsub(p.o, T);
         const RayTerms rterms = ray_terms(op, p.d, ra, L.scan_scale);
         BoxTerms bt;
@@ -2074,9 +2081,7 @@ RT_DEV void render_queue_stream_body(const Scene& sc, uint32_t* __restrict__ rgb
             for (uint32_t t = 0u; t < n_tiles && t < 64u; t++) {
                 float tn, tf;
                 box_span(bt, tboxes[2u * t], tboxes[2u * t + 1u], tn, tf);
-                const bool reach = active && !(tf < tn);
-                if (reach) lane_tiles |= 1ull << t;
-                if (__ballot(reach) != 0ull) mine_need |= 1ull << t;
+                if (__ballot(active && !(tf < tn)) != 0ull) mine_need |= 1ull << t;
             }
             if (lane == 0u && mine_need != 0ull) atomicOr(&vote[round & 1u], mine_need);
             __syncthreads();
@@ -2105,7 +2110,7 @@ RT_DEV void render_queue_stream_body(const Scene& sc, uint32_t* __restrict__ rgb
             // (no boxes, or a tile beyond the 64 that were voted on: every lane with a ray counts as reaching the tile)
             const bool voted = box_f4 && t < 64u;
             if (!voted || ((mine_need >> t) & 1ull))
-                scan_tile_stream(tile, count, (int)first, rterms, bt, p.o, p.d, ra, L.t_min, b, cand, st, active, voted ? ((lane_tiles >> t) & 1ull) != 0ull : active);
+                scan_tile_stream(tile, count, (int)first, rterms, bt, p.o, p.d, ra, L.t_min, b, cand, st, active);
         }
         drain(whole, 0, cand, p.o, p.d, ra, L.t_min, b, st);     // the segment's candidates, from all its tiles
         if (active) {
