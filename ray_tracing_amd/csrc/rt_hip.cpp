@@ -422,6 +422,14 @@ int launch_render(rt_ctx* c, const RtCamera* cam, const RtParams* p, RtLaunch L,
             waves = block / 64u;
             grid = (L.n_units + waves - 1u) / waves;
         }
+        if (!one_tile && p->block_dim == 0u) {
+            // the streaming kernel's wavefronts move through the tiles in lock step, and most of a round is waiting for
+            // the workgroup's slowest at the barriers: two wavefronts per workgroup (nine workgroups per compute unit)
+            // wait less than four (16,385-sphere frame: 64 threads 94 ms, 128: 87, 192: 106, 256: 111, 512: 186)
+            block = 128u;
+            waves = block / 64u;
+            grid = (L.n_units + waves - 1u) / waves;
+        }
         // the unit lists are the first thing to go where a workgroup's LDS (64 KiB) is short: 16 entries, 12, 8, none
         auto queue_lds = [&](unsigned cap) {
             return (one_tile ? c->n_padded * 32u + L.scan_blocks * 32u : RT_Q_STREAM_TILE * 16u + (L.scan_blocks ? RT_Q_STREAM_TILE + 32u + 16u : 0u)) +
@@ -443,8 +451,10 @@ int launch_render(rt_ctx* c, const RtCamera* cam, const RtParams* p, RtLaunch L,
             else if (L.scan_blocks != 0u && c->f_render_pool_boxes) { pool_f = c->f_render_pool_boxes; pool_name = "rt_render_pool_boxes"; }
             else { pool_f = c->f_render_pool; pool_name = "rt_render_pool"; L.scan_blocks = 0u; }
         }
-        if (L.ulist_cap != 0u) {
-            // (and the lists must not cost a workgroup per compute unit: a wave of occupancy is worth more)
+        if (L.ulist_cap != 0u && one_tile) {
+            // (and the lists must not cost a workgroup per compute unit: a wave of occupancy is worth more.  Not so where
+            // the list is streamed: without a unit list every camera ray scans the whole scene's camera-ray terms in
+            // global memory -- measured five times the frame time)
             hipFunction_t fq = L.pool_slots ? pool_f : f;
             auto resident_with = [&](unsigned cap) {
                 const unsigned bytes = L.pool_slots ? pool_lds(cap) : queue_lds(cap);
