@@ -514,6 +514,33 @@ def test_fold_order_runs_on_the_batch_kernels_and_on_the_pixel_kernel(oracle, rt
     hip.debug_schedule()
 
 
+def test_device_list_layouts_at_their_edges(oracle, rt, hip):
+    """The launcher sorts lists of 32 spheres and more in space and puts up to 30 large spheres behind the small ones'
+    last block.  Scenes at the edges of those rules -- 31, 32 and 33 spheres, a list that is one block and one sphere,
+    40 large spheres among 200 small ones (too many to set apart), 30 large ones (just few enough), only large ones --
+    against the checker bit for bit, chunked and fold order."""
+    rng = np.random.default_rng(123)
+
+    def scene(n_small, n_large):
+        n = n_small + n_large
+        sp = np.zeros(n, rt.SPHERE_DTYPE)
+        sp["center"] = rng.uniform(-8, 8, (n, 3)).astype(np.float32)
+        sp["radius"] = rng.uniform(0.2, 0.6, n).astype(np.float32)
+        big = rng.permutation(n)[:n_large]
+        sp["radius"][big] = rng.uniform(5.0, 9.0, n_large).astype(np.float32)
+        sp["center"][big] += (rng.uniform(-1, 1, (n_large, 3)) * 20.0).astype(np.float32)
+        sp["material"] = rng.choice([1, 2, 3], n, p=[0.5, 0.3, 0.2])
+        sp["albedo"] = rng.uniform(0.2, 1.0, (n, 3)).astype(np.float32)
+        sp["param"] = np.where(sp["material"] == 3, 1.5, rng.uniform(0.0, 0.6, n)).astype(np.float32)
+        return sp
+
+    cam = rt.Camera.look_at(1.5, 96, 60.0, (14.0, 6.0, 16.0), (0.0, 0.0, 0.0))
+    for n_small, n_large in ((31, 0), (32, 0), (33, 0), (32, 1), (200, 40), (200, 30), (0, 40), (70, 2)):
+        sp = scene(n_small, n_large)
+        check_render(oracle, hip, cam, sp, rt.DeviceGUI(samples_per_pixel=6, max_depth=12, seed=5, sample_chunk=1))
+        check_render(oracle, hip, cam, sp, rt.DeviceGUI(samples_per_pixel=5, max_depth=12, seed=6))
+
+
 def test_list_of_more_than_64_tiles(oracle, rt, hip):
     """40,001 spheres: 79 tiles of 512.  The workgroup's vote covers the first 64 tiles of a round; the tiles beyond
     are staged for everybody and every lane with a ray tests the boxes of their blocks.  Chunked and fold order against
