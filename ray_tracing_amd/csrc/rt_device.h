@@ -78,12 +78,15 @@ typedef struct RtLaunch {
 #ifndef RT_CAND_CAP
 #define RT_CAND_CAP 16u
 #endif
-// Kernel for sample_chunk = 1 (camera rays in batches): candidate slots per lane, 32-bit words per queued ray
-// spheres per LDS tile when that kernel streams a longer list (a multiple of 32: a tile is whole blocks).  Measured on
-// the 16,385-sphere scene with a box per tile and per block: 256: 226 ms, 512: 207 ms, 896: 205 ms (fewer barriers
-// against larger boxes); without boxes, when every tile was scanned: 512: 1,265 ms, 1024: 1,341 ms, 2048: 1,748 ms.
+// Kernel for sample_chunk = 1 (camera rays in batches): candidate slots per lane, 32-bit words per queued ray;
+// spheres per LDS tile when that kernel streams a longer list (a multiple of 32: a tile is whole blocks; at most 512:
+// a wavefront tests the boxes of a tile's blocks with 16 lanes).  Measured on the 16,385-sphere scene, with a box per
+// tile and per block and the launcher's workgroup size of the time: 256-thread workgroups 256: 226 ms, 512: 207 ms,
+// 896: 205 ms; later, workgroups of two wavefronts 512: 87 ms, 384: 88, 448: 93; workgroups of ONE wavefront (nothing
+// to wait for at the tile barriers, and small tiles let 18 of them share a compute unit's LDS) 512: 94 ms, 256: 74 ms.
+// Without boxes, when every tile was scanned: 512: 1,265 ms, 1024: 1,341 ms, 2048: 1,748 ms.
 #ifndef RT_Q_STREAM_TILE
-#define RT_Q_STREAM_TILE 512u
+#define RT_Q_STREAM_TILE 256u
 #endif
 // A block of 32 spheres reached by at most this many lanes of a wavefront is scanned lanes-over-spheres, one reaching ray at
 // a time (scan_tile); beyond it the 64 rays scan the block's spheres side by side.

@@ -423,10 +423,11 @@ int launch_render(rt_ctx* c, const RtCamera* cam, const RtParams* p, RtLaunch L,
             grid = (L.n_units + waves - 1u) / waves;
         }
         if (!one_tile && p->block_dim == 0u) {
-            // the streaming kernel's wavefronts move through the tiles in lock step, and most of a round is waiting for
-            // the workgroup's slowest at the barriers: two wavefronts per workgroup (nine workgroups per compute unit)
-            // wait less than four (16,385-sphere frame: 64 threads 94 ms, 128: 87, 192: 106, 256: 111, 512: 186)
-            block = 128u;
+            // the streaming kernel's wavefronts move through the tiles in lock step, and most of a round was waiting for
+            // the workgroup's slowest at the barriers: workgroups of ONE wavefront wait for nobody, and with 256-sphere
+            // tiles 18 of them share a compute unit's LDS (16,385-sphere frame, 512-sphere tiles: 64 threads 94 ms, 128:
+            // 87, 192: 106, 256: 111, 512: 186; 256-sphere tiles: 64 threads 74 ms, 128: 90)
+            block = 64u;
             waves = block / 64u;
             grid = (L.n_units + waves - 1u) / waves;
         }

@@ -2063,54 +2063,53 @@ RT_DEV void render_queue_stream_body(const Scene& sc, uint32_t* __restrict__ rgb
         b.idx = -1;
         bool finished = false;                                   // a bounce path of this lane ended in this round
         const float ra = vdot(p.d, p.d);
-        // Which tiles does anybody need?  Every lane tests its ray against the boxes of all tiles (wave-uniform reads
-        // from global memory), the wavefronts put their answers together in LDS, and a tile nobody's ray reaches is
-        // neither staged nor waited for: one barrier for the vote instead of two per tile (the first 64 tiles; any
-        // beyond are staged as before).  The two vote words take turns: the one not in use is cleared after the
-        // barrier, a round before it is voted in again.
-        unsigned long long needed = ~0ull;
-        unsigned long long mine_need = 0ull;                        // tiles some lane of this wavefront reaches
+        // Which tiles does anybody need?  Every lane tests its ray against the boxes of the tiles (wave-uniform reads
+        // from global memory), 64 tiles at a time; the wavefronts put their answers together in LDS, and a tile nobody's
+        // ray reaches is neither staged nor waited for: one barrier for the vote instead of two per tile.  The two vote
+        // words take turns: the one not in use is cleared after the barrier, a vote before it is used again.
         const V3 op = vsub(p.o, T);
         const RayTerms rterms = ray_terms(op, p.d, ra, L.scan_scale);
         BoxTerms bt;
         bt.inv = bt.n_lo = bt.n_hi = v3(0.0f, 0.0f, 0.0f);
-        if (box_f4) {
-            bt = box_terms(op, rterms.uf, L.scan_scale);
-            const float4* tboxes = sc.geom + L.n_padded + 2u * L.scan_blocks;
-            const uint32_t n_tiles = (L.n_padded + RT_Q_STREAM_TILE - 1u) / RT_Q_STREAM_TILE;
-            for (uint32_t t = 0u; t < n_tiles && t < 64u; t++) {
-                float tn, tf;
-                box_span(bt, tboxes[2u * t], tboxes[2u * t + 1u], tn, tf);
-                if (__ballot(active && !(tf < tn)) != 0ull) mine_need |= 1ull << t;
-            }
-            if (lane == 0u && mine_need != 0ull) atomicOr(&vote[round & 1u], mine_need);
-            __syncthreads();
-            needed = vote[round & 1u];
-            if (threadIdx.x == 0u) vote[(round & 1u) ^ 1u] = 0ull;
-            round++;
-#ifdef RT_STATS_VOTE
-            if (threadIdx.x == 0u) { st.raw(5, (uint32_t)__popcll(needed)); st.raw(7, 1u); st.raw(6, (uint32_t)__popcll(mine_need)); }
-#endif
-        }
+        if (box_f4) bt = box_terms(op, rterms.uf, L.scan_scale);
+        const float4* tboxes = sc.geom + L.n_padded + 2u * L.scan_blocks;
+        const uint32_t n_tiles = (L.n_padded + RT_Q_STREAM_TILE - 1u) / RT_Q_STREAM_TILE;
         bool staged = false;
-        for (uint32_t first = 0u, t = 0u; first < L.n_padded; first += RT_Q_STREAM_TILE, t++) {
-            uint32_t count = L.n_padded - first;
-            if (count > RT_Q_STREAM_TILE) count = RT_Q_STREAM_TILE;
-            if (t < 64u && !((needed >> t) & 1ull)) continue;    // (the same for the whole workgroup)
-            if (staged) __syncthreads();                         // previous tile fully scanned
-            staged = true;
-            for (uint32_t i = threadIdx.x; i < count; i += blockDim.x) geo[i] = sc.geom[first + i];
-            for (uint32_t i = threadIdx.x; i < box_f4; i += blockDim.x) {   // (2 float4 per 32 spheres, then the tile's own two)
-                if (i >= box_f4 - 2u) box[i] = sc.geom[L.n_padded + 2u * L.scan_blocks + 2u * (first / S) + (i - (box_f4 - 2u))];
-                else if (first / 16u + i < 2u * L.scan_blocks) box[i] = sc.geom[L.n_padded + first / 16u + i];
+        for (uint32_t g0 = 0u; g0 < n_tiles; g0 += 64u) {
+            const uint32_t gn = n_tiles - g0 < 64u ? n_tiles - g0 : 64u;
+            unsigned long long needed = ~0ull;                      // tiles of this group some lane of the workgroup reaches
+            unsigned long long mine_need = ~0ull;                   // ... some lane of this wavefront
+            if (box_f4) {
+                mine_need = 0ull;
+                for (uint32_t t = 0u; t < gn; t++) {
+                    float tn, tf;
+                    box_span(bt, tboxes[2u * (g0 + t)], tboxes[2u * (g0 + t) + 1u], tn, tf);
+                    if (__ballot(active && !(tf < tn)) != 0ull) mine_need |= 1ull << t;
+                }
+                if (lane == 0u && mine_need != 0ull) atomicOr(&vote[round & 1u], mine_need);
+                __syncthreads();
+                needed = vote[round & 1u];
+                if (threadIdx.x == 0u) vote[(round & 1u) ^ 1u] = 0ull;
+                round++;
             }
-            __syncthreads();
-            const Tile tile = {geo, sc.exact, box_f4 ? box : nullptr, orig_of(L, sc.mat), box_f4 ? box + (box_f4 - 2u) : nullptr};   // exact-test data: the whole list's, in global memory
-            // every lane of a wavefront that has a ray for this tile: see scan_tile
-            // (no boxes, or a tile beyond the 64 that were voted on: every lane with a ray counts as reaching the tile)
-            const bool voted = box_f4 && t < 64u;
-            if (!voted || ((mine_need >> t) & 1ull))
-                scan_tile_stream(tile, count, (int)first, rterms, bt, p.o, p.d, ra, L.t_min, b, cand, st, active);
+            for (uint32_t t = 0u; t < gn; t++) {
+                if (!((needed >> t) & 1ull)) continue;               // (the same for the whole workgroup)
+                const uint32_t first = (g0 + t) * RT_Q_STREAM_TILE;
+                uint32_t count = L.n_padded - first;
+                if (count > RT_Q_STREAM_TILE) count = RT_Q_STREAM_TILE;
+                if (staged) __syncthreads();                         // previous tile fully scanned
+                staged = true;
+                for (uint32_t i = threadIdx.x; i < count; i += blockDim.x) geo[i] = sc.geom[first + i];
+                for (uint32_t i = threadIdx.x; i < box_f4; i += blockDim.x) {   // (2 float4 per 32 spheres, then the tile's own two)
+                    if (i >= box_f4 - 2u) box[i] = tboxes[2u * (g0 + t) + (i - (box_f4 - 2u))];
+                    else if (first / 16u + i < 2u * L.scan_blocks) box[i] = sc.geom[L.n_padded + first / 16u + i];
+                }
+                __syncthreads();
+                const Tile tile = {geo, sc.exact, box_f4 ? box : nullptr, orig_of(L, sc.mat), box_f4 ? box + (box_f4 - 2u) : nullptr};   // exact-test data: the whole list's, in global memory
+                // every lane of a wavefront that has a ray for this tile: see scan_tile
+                if ((mine_need >> t) & 1ull)
+                    scan_tile_stream(tile, count, (int)first, rterms, bt, p.o, p.d, ra, L.t_min, b, cand, st, active);
+            }
         }
         drain(whole, 0, cand, p.o, p.d, ra, L.t_min, b, st);     // the segment's candidates, from all its tiles
         if (active) {
