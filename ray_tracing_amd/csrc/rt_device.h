@@ -83,7 +83,8 @@ typedef struct RtLaunch {
 // a wavefront tests the boxes of a tile's blocks with 16 lanes).  Measured on the 16,385-sphere scene, with a box per
 // tile and per block and the launcher's workgroup size of the time: 256-thread workgroups 256: 226 ms, 512: 207 ms,
 // 896: 205 ms; later, workgroups of two wavefronts 512: 87 ms, 384: 88, 448: 93; workgroups of ONE wavefront (nothing
-// to wait for at the tile barriers, and small tiles let 18 of them share a compute unit's LDS) 512: 94 ms, 256: 74 ms.
+// to wait for at the tile barriers, and small tiles let 18 of them share a compute unit's LDS) 512: 94 ms, 256: 73 ms, 128 (20
+// resident, twice the tile boxes to vote on): 88 ms.
 // Without boxes, when every tile was scanned: 512: 1,265 ms, 1024: 1,341 ms, 2048: 1,748 ms.
 #ifndef RT_Q_STREAM_TILE
 #define RT_Q_STREAM_TILE 256u
@@ -97,7 +98,9 @@ typedef struct RtLaunch {
 #ifndef RT_SPARSE_TILE_MAX
 #define RT_SPARSE_TILE_MAX 12u
 #endif
-// waves per SIMD the streaming camera-ray-batch kernels are built for
+// waves per SIMD the streaming camera-ray-batch kernels are built for (16,385-sphere frame: 5 -- 96 registers, 72 bytes
+// of scratch per lane -- 73 ms; 4 -- 128 registers, 12 bytes -- 77 ms: the kernel waits on memory and LDS, a resident
+// wavefront more is worth more than the spills cost while they stay in L2)
 #ifndef RT_STREAM_WAVES
 #define RT_STREAM_WAVES 5
 #endif
