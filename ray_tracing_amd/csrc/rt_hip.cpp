@@ -678,7 +678,7 @@ void rt_destroy(rt_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->comm && rccl()->CommDestroy) (void)rccl()->CommDestroy(c->comm);
-    void* bufs[] = {c->d_geom, c->d_exact, c->d_shade, c->d_mat, c->d_camterms, c->d_rgba, c->d_linear, c->d_hits, c->d_counter, c->d_tiles, c->d_frame, c->d_status, c->d_fold};
+    void* bufs[] = {c->d_geom /* holds the scene's other arrays too */, c->d_rgba, c->d_linear, c->d_hits, c->d_counter, c->d_tiles, c->d_frame, c->d_status, c->d_fold};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -867,7 +867,7 @@ int rt_upload_scene(rt_ctx* c, const RtSphere* spheres, uint32_t n) {
     // for its ray; the exact test's tolerance is below 2^-11 |c - o|)
     const uint32_t n_blocks = (n_padded + 31u) / 32u;
     const uint32_t n_tiles = (n_padded + RT_Q_STREAM_TILE - 1u) / RT_Q_STREAM_TILE;   // ... and one box per tile of the streaming kernels behind those
-    std::vector<float> geom(((size_t)n_padded + 2u * n_blocks + 2u * n_tiles) * 4), exact((size_t)n_padded * 4), shade((size_t)n_padded * 12, 0.0f);
+    std::vector<float> geom(((size_t)n_padded + 2u * n_blocks + 2u * n_tiles + n_blocks) * 4), exact((size_t)n_padded * 4), shade((size_t)n_padded * 12, 0.0f);
     std::vector<uint32_t> mat((size_t)n_padded * 2u);
     for (uint32_t b = 0; b < n_blocks + n_tiles; b++) {
         float* lo4 = &geom[4 * ((size_t)n_padded + 2u * b)];
@@ -930,16 +930,38 @@ int rt_upload_scene(rt_ctx* c, const RtSphere* spheres, uint32_t n) {
             mat[i] = RT_MAT_DIFFUSE;
         }
     }
+    // ... and behind the tiles' boxes a ball per block that holds the block's box, {cb, rb (1 + 2^-7)}: what the pixel
+    // units' lists of a streamed scene test before they look at a block's spheres (unit_list in rt_kernels.hip).  cb is
+    // the box's centre as rounded to single precision, rb half the diagonal plus that rounding, rounded up.
+    for (uint32_t b = 0; b < n_blocks; b++) {
+        const float* lo4 = &geom[4 * ((size_t)n_padded + 2u * b)];
+        float* ball = &geom[4 * ((size_t)n_padded + 2u * n_blocks + 2u * n_tiles + b)];
+        double d2 = 0.0, c1 = 0.0;
+        bool finite = true;
+        for (int k = 0; k < 3; k++) {
+            finite = finite && std::isfinite(lo4[k]) && std::isfinite(lo4[4 + k]) && lo4[k] <= lo4[4 + k];
+            const double mid = 0.5 * ((double)lo4[k] + (double)lo4[4 + k]), ext = (double)lo4[4 + k] - (double)lo4[k];
+            ball[k] = (float)mid;
+            d2 += ext * ext;
+            c1 += std::fabs(mid);
+        }
+        const double rb = (0.5 * std::sqrt(d2) * (1.0 + 0x1p-40) + 0x1p-22 * c1) * (1.0 + 0x1p-7);
+        ball[3] = std::nextafter((float)rb, INFINITY);
+        if (!finite || !std::isfinite(ball[3])) { ball[0] = ball[1] = ball[2] = 0.0f; ball[3] = INFINITY; }
+    }
     size_t bytes = (size_t)n_padded * 16u;
-    const size_t geom_bytes = bytes + ((size_t)n_blocks + n_tiles) * 32u;
-    void** owned[] = {&c->d_geom, &c->d_exact, &c->d_shade, &c->d_mat, &c->d_camterms};
-    for (void** p : owned) if (*p) { RT_HIP(c, hipFree(*p)); *p = nullptr; }
+    const size_t geom_bytes = bytes + ((size_t)n_blocks + n_tiles) * 32u + (size_t)n_blocks * 16u;
+    // One allocation, the arrays at offsets that follow from n_padded alone (SceneAt in rt_kernels.hip finds them from
+    // the first address): filter data with the boxes and balls, exact-test data, shading data (3 float4 per sphere),
+    // the launch's camera-ray terms, then the material tags and the caller's index of each device sphere.
+    if (c->d_geom) { RT_HIP(c, hipFree(c->d_geom)); }
+    c->d_geom = c->d_exact = c->d_shade = c->d_mat = c->d_camterms = nullptr;
     c->have_scene = false;
-    RT_HIP(c, hipMalloc(&c->d_geom, geom_bytes));
-    RT_HIP(c, hipMalloc(&c->d_exact, bytes));
-    RT_HIP(c, hipMalloc(&c->d_shade, 3 * bytes));
-    RT_HIP(c, hipMalloc(&c->d_mat, (size_t)n_padded * 8u));                       // material tags, then the caller's index of each device sphere
-    RT_HIP(c, hipMalloc(&c->d_camterms, bytes));
+    RT_HIP(c, hipMalloc(&c->d_geom, geom_bytes + 5 * bytes + (size_t)n_padded * 8u));
+    c->d_exact = (char*)c->d_geom + geom_bytes;
+    c->d_shade = (char*)c->d_exact + bytes;
+    c->d_camterms = (char*)c->d_shade + 3 * bytes;
+    c->d_mat = (char*)c->d_camterms + bytes;
     RT_HIP(c, hipMemcpy(c->d_geom, geom.data(), geom_bytes, hipMemcpyHostToDevice));
     RT_HIP(c, hipMemcpy(c->d_exact, exact.data(), bytes, hipMemcpyHostToDevice));
     RT_HIP(c, hipMemcpy(c->d_shade, shade.data(), 3 * bytes, hipMemcpyHostToDevice));

@@ -746,12 +746,101 @@ struct UnitList { float4* terms; uint16_t* idx; };             // RtLaunch.ulist
 
 // geom: {c - T, .} and exact: {., r*r} per sphere (global memory); terms: the launch's camera-ray terms (LDS copy, or
 // global memory where the sphere list is streamed), copied for the listed spheres.
+// BLOCKS (the streaming kernels, whose lists run to tens of thousands of spheres): the boxes of the blocks of 32 are
+// tested first, 64 blocks per step, and only the spheres of the blocks that pass are looked at, a block per step.  A
+// block's box holds its spheres whole, so does the ball round the box (centre cb, radius rb = half the diagonal), and
+// the sphere test above carries over with the ball in the sphere's place and its slacks summed instead of squared:
+// a ray the exact test can accept passes within r_eff <= r (1 + 2^-17) + 2^-9 |q| of its sphere's centre, |q| <= |qb| +
+// rb, so within rb (1 + 2^-8) + 2^-9 |qb| of cb; a block is skipped if
+//     dist_b > bound_b   or   u.qb < -bound_b,     bound_b = rb (1 + 2^-7) + (|qb| + rb) (s + 2^-8) + 2^-19 (|o'| + |cb|)
+// (the second: u.q <= u.qb + |c' - cb| < -bound_b + rb - r, which is below the sphere's own -bound).  The host stores
+// the ball per block, {cb, rb (1 + 2^-7)}, the radius rounded up and with the rounding of cb added; an empty block or
+// one with a box that is not finite has rb = +inf and passes; its padding spheres fail the sphere test.
+struct UnitBundle { float ux, uy, uz, opx, opy, opz, s; };     // the unit's central direction, o - T, and the bundle's sine
+
+// The scan of unit_list.
+template <bool BLOCKS>
+RT_DEV uint32_t unit_list_scan(const float4* __restrict__ geom, const float4* __restrict__ exact, const float4* terms, float4* ul_terms,
+                               uint16_t* ul_idx, UnitBundle ub, uint32_t n_padded, uint32_t scan_blocks, uint32_t ulist_cap, uint32_t lane) {
+    const float ux = ub.ux, uy = ub.uy, uz = ub.uz, opx = ub.opx, opy = ub.opy, opz = ub.opz, s = ub.s;
+    const float o_abs = 0x1p-20f * (fabsf(opx) + fabsf(opy) + fabsf(opz));
+    uint32_t n = 0u;
+    auto sphere_passes = [&](uint32_t i) {
+        const float4 g = geom[i];
+        const float rr = exact[i].w;
+        const float qx = g.x - opx, qy = g.y - opy, qz = g.z - opz;
+        const float qq = (fmaf(qz, qz, fmaf(qy, qy, qx * qx))) * (1.0f + 0x1p-20f);
+        const float t = fmaf(uz, qz, fmaf(uy, qy, ux * qx));
+        const float kx = fmaf(qy, uz, -(qz * uy)), ky = fmaf(qz, ux, -(qx * uz)), kz = fmaf(qx, uy, -(qy * ux));
+        const float dist2 = fmaf(kz, kz, fmaf(ky, ky, kx * kx));
+        const float r_eff = __builtin_amdgcn_sqrtf(fmaf(rr, 1.0f + 0x1p-17f, 0x1p-18f * qq) * (1.0f + 0x1p-20f)) * (1.0f + 0x1p-20f);
+        const float q_len = __builtin_amdgcn_sqrtf(qq) * (1.0f + 0x1p-20f);
+        const float bound = (fmaf(q_len, s, r_eff) + fmaf(0x1p-20f, fabsf(g.x) + fabsf(g.y) + fabsf(g.z), o_abs)) * (1.0f + 0x1p-20f);
+        return !(dist2 > bound * bound) && !(t < -bound) && rr != -INFINITY;   // (r*r = -inf: padding)
+    };
+    // appends the passing lanes' spheres in lane order; false: the list is full
+    auto append = [&](bool pass, uint32_t i) {
+        const unsigned long long m = __ballot(pass);
+        const uint32_t cnt = (uint32_t)__popcll(m);
+        if (n + cnt > ulist_cap) return false;
+        if (pass) {
+            const uint32_t r = n + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            ul_terms[r] = terms[i];
+            ul_idx[r] = (uint16_t)i;
+        }
+        n += cnt;
+        return true;
+    };
+    if (BLOCKS && scan_blocks != 0u) {
+        // per block {cb, rb (1 + 2^-7) rounded up}, behind the blocks' and the tiles' boxes (rt_upload_scene)
+        const float4* ball = geom + n_padded + 2u * scan_blocks + 2u * ((n_padded + RT_Q_STREAM_TILE - 1u) / RT_Q_STREAM_TILE);
+        for (uint32_t first = 0u; first < scan_blocks; first += 64u) {
+            const uint32_t b = first + lane;
+            bool reach = false;
+            if (b < scan_blocks) {
+                const float4 g = ball[b];
+                const float qx = g.x - opx, qy = g.y - opy, qz = g.z - opz;
+                const float q_len = __builtin_amdgcn_sqrtf(fmaf(qz, qz, fmaf(qy, qy, qx * qx))) * (1.0f + 0x1p-18f);
+                const float t = fmaf(uz, qz, fmaf(uy, qy, ux * qx));
+                const float kx = fmaf(qy, uz, -(qz * uy)), ky = fmaf(qz, ux, -(qx * uz)), kz = fmaf(qx, uy, -(qy * ux));
+                const float dist2 = fmaf(kz, kz, fmaf(ky, ky, kx * kx));
+                const float bound = (fmaf(q_len + g.w, s + 0x1p-8f, g.w) + fmaf(0x1p-19f, fabsf(g.x) + fabsf(g.y) + fabsf(g.z), 2.0f * o_abs)) * (1.0f + 0x1p-18f);
+                reach = !(dist2 > bound * bound) && !(t < -bound);
+            }
+            unsigned long long todo = __ballot(reach);
+            while (todo) {                                        // wave-uniform: a block per step, lowest first
+                const uint32_t i = (first + (uint32_t)__builtin_ctzll(todo)) * 32u + lane;
+                todo &= todo - 1ull;
+                const bool pass = lane < 32u && i < n_padded && sphere_passes(i);
+                if (!append(pass, i)) return RT_UL_NONE;
+            }
+        }
+    } else {
+        for (uint32_t first = 0u; first < n_padded; first += 64u) {
+            const uint32_t i = first + lane;
+            const bool pass = i < n_padded && sphere_passes(i);
+            if (!append(pass, i)) return RT_UL_NONE;
+        }
+    }
+    if (n & 1u) {                                                 // even, as the scans' last step wants it (the capacity is even)
+        if (lane == 0u) { ul_terms[n] = make_float4(0.0f, 0.0f, 0.0f, INFINITY); ul_idx[n] = 0u; }
+        n++;
+    }
+    return n;
+}
+
+template <bool BLOCKS = false>
 RT_DEV uint32_t unit_list(const float4* __restrict__ geom, const float4* __restrict__ exact, const float4* terms, const RtCamera& cam,
                           const RtLaunch& L, uint32_t x0, uint32_t y0, const UnitList& ul, uint32_t lane) {
     float ux, uy, uz, opx, opy, opz, s;
     {
-        const double fxc = (double)x0 + 0.5 * ((double)L.unit_w - 0.5), fyc = (double)y0 + 0.5 * ((double)L.unit_h - 0.5);
-        const double ox = cam.center[0], oy = cam.center[1], oz = cam.center[2];
+        // (the launch's constants pass through an empty volatile asm: otherwise the parts of the sums below that do not
+        // depend on the unit are computed once, before the render loop, and five doubles sit in every lane's scratch)
+        uint32_t unit_w = L.unit_w, unit_h = L.unit_h;
+        float cx = cam.center[0], cy = cam.center[1], cz = cam.center[2];
+        asm volatile("" : "+s"(unit_w), "+s"(unit_h), "+s"(cx), "+s"(cy), "+s"(cz));
+        const double fxc = (double)x0 + 0.5 * ((double)unit_w - 0.5), fyc = (double)y0 + 0.5 * ((double)unit_h - 0.5);
+        const double ox = cx, oy = cy, oz = cz;
         const double dx = ((double)cam.pixel00_loc[0] - ox) + (fxc * (double)cam.pixel_delta_u[0] + fyc * (double)cam.pixel_delta_v[0]);
         const double dy = ((double)cam.pixel00_loc[1] - oy) + (fxc * (double)cam.pixel_delta_u[1] + fyc * (double)cam.pixel_delta_v[1]);
         const double dz = ((double)cam.pixel00_loc[2] - oz) + (fxc * (double)cam.pixel_delta_u[2] + fyc * (double)cam.pixel_delta_v[2]);
@@ -763,48 +852,39 @@ RT_DEV uint32_t unit_list(const float4* __restrict__ geom, const float4* __restr
         ux = (float)(dx * inv); uy = (float)(dy * inv); uz = (float)(dz * inv);
         opx = (float)(ox - (double)L.translate[0]); opy = (float)(oy - (double)L.translate[1]); opz = (float)(oz - (double)L.translate[2]);
     }
-    const float o_abs = 0x1p-20f * (fabsf(opx) + fabsf(opy) + fabsf(opz));
-    uint32_t n = 0u;
-    for (uint32_t first = 0u; first < L.n_padded; first += 64u) {
-        const uint32_t i = first + lane;
-        bool pass = false;
-        if (i < L.n_padded) {
-            const float4 g = geom[i];
-            const float rr = exact[i].w;
-            const float qx = g.x - opx, qy = g.y - opy, qz = g.z - opz;
-            const float qq = (fmaf(qz, qz, fmaf(qy, qy, qx * qx))) * (1.0f + 0x1p-20f);
-            const float t = fmaf(uz, qz, fmaf(uy, qy, ux * qx));
-            const float kx = fmaf(qy, uz, -(qz * uy)), ky = fmaf(qz, ux, -(qx * uz)), kz = fmaf(qx, uy, -(qy * ux));
-            const float dist2 = fmaf(kz, kz, fmaf(ky, ky, kx * kx));
-            const float r_eff = __builtin_amdgcn_sqrtf(fmaf(rr, 1.0f + 0x1p-17f, 0x1p-18f * qq) * (1.0f + 0x1p-20f)) * (1.0f + 0x1p-20f);
-            const float q_len = __builtin_amdgcn_sqrtf(qq) * (1.0f + 0x1p-20f);
-            const float bound = (fmaf(q_len, s, r_eff) + fmaf(0x1p-20f, fabsf(g.x) + fabsf(g.y) + fabsf(g.z), o_abs)) * (1.0f + 0x1p-20f);
-            pass = !(dist2 > bound * bound) && !(t < -bound) && rr != -INFINITY;   // (r*r = -inf: padding)
-        }
-        const unsigned long long m = __ballot(pass);
-        const uint32_t cnt = (uint32_t)__popcll(m);
-        if (n + cnt > L.ulist_cap) return RT_UL_NONE;
-        if (pass) {
-            const uint32_t r = n + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-            ul.terms[r] = terms[i];
-            ul.idx[r] = (uint16_t)i;
-        }
-        n += cnt;
-    }
-    if (n & 1u) {                                                 // even, as the scans' last step wants it (the capacity is even)
-        if (lane == 0u) { ul.terms[n] = make_float4(0.0f, 0.0f, 0.0f, INFINITY); ul.idx[n] = 0u; }
-        n++;
-    }
-    return n;
+    const UnitBundle ub = {ux, uy, uz, opx, opy, opz, s};
+    return unit_list_scan<BLOCKS>(geom, exact, terms, ul.terms, ul.idx, ub, L.n_padded, L.scan_blocks, L.ulist_cap, lane);
 }
 
 // ---------------------------------------------------------------- shading
 struct Scene {
     const float4* __restrict__ geom;    // filter data {c - T, m} per sphere, n_padded entries
-    const float4* __restrict__ exact;   // {c, r*r} per sphere, n_padded entries
-    const float4* __restrict__ shade;   // per sphere two float4: {cx, cy, cz, radius}, {albedo r, g, b, fuzz | ior}; after the
+    const float4* __restrict__ exact_;  // {c, r*r} per sphere, n_padded entries
+    const float4* __restrict__ shade_;  // per sphere two float4: {cx, cy, cz, radius}, {albedo r, g, b, fuzz | ior}; after the
                                         // 2 * n_padded of those, one float4 per sphere with the glass constants (see scatter)
-    const uint32_t* __restrict__ mat;   // material tag per sphere
+    const uint32_t* __restrict__ mat_;  // material tag per sphere
+    const float4* __restrict__ camterms_;   // the launch's camera-ray terms per sphere (rt_camera_terms)
+    RT_DEV const float4* exact() const { return exact_; }
+    RT_DEV const float4* shade() const { return shade_; }
+    RT_DEV const uint32_t* mat() const { return mat_; }
+    RT_DEV const float4* camterms() const { return camterms_; }
+};
+
+// The same arrays found from the first one: rt_upload_scene puts a scene's arrays into one allocation -- filter data,
+// the blocks' and tiles' boxes and the blocks' balls, then exact-test data, shading data, camera-ray terms, material
+// tags -- so a kernel can hold ONE address and the sphere count where Scene holds five addresses.  The streaming
+// kernels do: ten scalar registers they do not have (the values were kept in vector registers, and those in scratch).
+// The count passes through an empty volatile asm at every use, so the sums are made where they are needed (a few
+// scalar instructions) instead of once and kept.
+struct SceneAt {
+    const float4* __restrict__ geom;
+    uint32_t n_padded;
+    RT_DEV uint32_t n() const { uint32_t v = n_padded; asm volatile("" : "+s"(v)); return v; }
+    RT_DEV static uint32_t head(uint32_t v) { return v + 3u * ((v + 31u) >> 5) + 2u * ((v + RT_Q_STREAM_TILE - 1u) / RT_Q_STREAM_TILE); }
+    RT_DEV const float4* exact() const { const uint32_t v = n(); return geom + head(v); }
+    RT_DEV const float4* shade() const { const uint32_t v = n(); return geom + (head(v) + v); }
+    RT_DEV const float4* camterms() const { const uint32_t v = n(); return geom + (head(v) + 4u * v); }
+    RT_DEV const uint32_t* mat() const { const uint32_t v = n(); return (const uint32_t*)(geom + (head(v) + 5u * v)); }
 };
 
 struct HitInfo { V3 p, n; bool front; };
@@ -1107,13 +1187,13 @@ RT_DEV void render_body(const Scene& sc, uint32_t* __restrict__ rgba, float4* __
     const uint32_t n_items = L.max_depth > 0u ? P * L.n_chunks : 0u;   // per unit
     const bool exact_sum = L.n_chunks > 1u;
 
-    Tile tile = {rt_lds, rt_lds + tile_capacity(L), nullptr, orig_of(L, sc.mat)};
+    Tile tile = {rt_lds, rt_lds + tile_capacity(L), nullptr, orig_of(L, sc.mat())};
     const V3 T = ld3(L.translate);
     // per wavefront and slot: [P][3] 64-bit words, fixed-point sums (exact_sum) or the fp32 run sum bits
     unsigned long long* accum = accum_base(L) + wave * (6u * P);
     for (uint32_t k = lane; k < 6u * P; k += 64u) accum[k] = 0ull;
     if (!MULTI) {
-        tile = stage_tile(L, sc.geom, sc.exact, orig_of(L, sc.mat), 0u, L.n_padded);
+        tile = stage_tile(L, sc.geom, sc.exact(), orig_of(L, sc.mat()), 0u, L.n_padded);
         __syncthreads();
     }
 
@@ -1213,7 +1293,7 @@ RT_DEV void render_body(const Scene& sc, uint32_t* __restrict__ rgba, float4* __
                 uint32_t count = L.n_padded - first;
                 if (count > RT_TILE_SPHERES) count = RT_TILE_SPHERES;
                 if (first) __syncthreads();                      // previous tile fully scanned
-                tile = stage_tile(L, sc.geom, sc.exact, orig_of(L, sc.mat), first, count);
+                tile = stage_tile(L, sc.geom, sc.exact(), orig_of(L, sc.mat()), first, count);
                 __syncthreads();
                 if (active) scan_tile<false>(tile, count, (int)first, T, L.scan_scale, o, d, a, L.t_min, b, cand, st);
             }
@@ -1226,11 +1306,11 @@ RT_DEV void render_body(const Scene& sc, uint32_t* __restrict__ rgba, float4* __
             bool path_done;
             V3 color;
             if (b.idx >= 0) {                                    // ray.cu:35-40
-                const float4 cr = sc.shade[2 * b.idx];
-                const float4 al = sc.shade[2 * b.idx + 1];
-                const uint32_t mat = sc.mat[b.idx];
+                const float4 cr = sc.shade()[2 * b.idx];
+                const float4 al = sc.shade()[2 * b.idx + 1];
+                const uint32_t mat = sc.mat()[b.idx];
                 HitInfo h = finish_hit(cr, b.t, o, d, flags);
-                V3 nd = scatter(mat, al.w, sc.shade + 2u * L.n_padded + (uint32_t)b.idx, d, h, seed, it.pixel, it.s, seg + 1u, flags, st);
+                V3 nd = scatter(mat, al.w, sc.shade() + 2u * L.n_padded + (uint32_t)b.idx, d, h, seed, it.pixel, it.s, seg + 1u, flags, st);
                 o = h.p;
                 d = nd;
                 if (flags & RT_FLAG_BAND_ALBEDO) {
@@ -1319,15 +1399,16 @@ struct Path { V3 o, d, thr; uint32_t seg, nb; };
 
 // Shades the segment that ended in `b`: scatter at the hit (ray.cu:35-40) or sky colour (ray.cu:43-45,
 // lib.rs:195-205).  Returns true when the path is over, with its colour.
-RT_DEV bool shade_segment(const Scene& sc, const RtLaunch& L, uint64_t seed, const Best& b, uint32_t pixel, uint32_t s,
+template <class SC>
+RT_DEV bool shade_segment(const SC& sc, const RtLaunch& L, uint64_t seed, const Best& b, uint32_t pixel, uint32_t s,
                           float band, Path& p, V3& color, Stats& st) {
     const uint32_t flags = L.flags;
     if (b.idx >= 0) {
-        const float4 cr = sc.shade[2 * b.idx];
-        const float4 al = sc.shade[2 * b.idx + 1];
-        const uint32_t mat = sc.mat[b.idx];
+        const float4 cr = sc.shade()[2 * b.idx];
+        const float4 al = sc.shade()[2 * b.idx + 1];
+        const uint32_t mat = sc.mat()[b.idx];
         HitInfo h = finish_hit(cr, b.t, p.o, p.d, flags);
-        V3 nd = scatter(mat, al.w, sc.shade + 2u * L.n_padded + (uint32_t)b.idx, p.d, h, seed, pixel, s, p.seg + 1u, flags, st);
+        V3 nd = scatter(mat, al.w, sc.shade() + 2u * L.n_padded + (uint32_t)b.idx, p.d, h, seed, pixel, s, p.seg + 1u, flags, st);
         p.o = h.p;
         p.d = nd;
         if (flags & RT_FLAG_BAND_ALBEDO) p.nb++;
@@ -1369,7 +1450,8 @@ RT_DEV void add_sample(unsigned long long* acc, uint32_t P, uint32_t pixslot, ui
 }
 
 // Queue entry j becomes the lane's path: the ray that left the camera ray's hit, one segment done.
-RT_DEV void take_queued(const Scene& sc, const RtLaunch& L, const uint32_t* q, uint32_t j, const Slot& u0, const Slot& u1,
+template <class SC>
+RT_DEV void take_queued(const SC& sc, const RtLaunch& L, const uint32_t* q, uint32_t j, const Slot& u0, const Slot& u1,
                         Path& p, uint32_t& s, uint32_t& pixel, uint32_t& pixslot, float& band) {
     const uint32_t P = L.unit_w * L.unit_h;
     p.o = v3(__uint_as_float(q[j]), __uint_as_float(q[64u + j]), __uint_as_float(q[128u + j]));
@@ -1388,7 +1470,7 @@ RT_DEV void take_queued(const Scene& sc, const RtLaunch& L, const uint32_t* q, u
         band = band_of(L, x);
         p.nb = 1u;
     } else {
-        const float4 al = sc.shade[2u * sphere + 1u];
+        const float4 al = sc.shade()[2u * sphere + 1u];
         p.thr = v3(al.x, al.y, al.z);                            // 1 * albedo (ray.cu:37)
         p.nb = 0u;
     }
@@ -1411,8 +1493,8 @@ RT_DEV uint32_t queue_rays(uint32_t* q, bool cont, const Path& p, uint32_t s, ui
 // number i / P).  Called by the whole wavefront.  Finished samples (miss, depth limit, pixel outside the
 // image) are counted in `completed`; the others leave a ray in the queue, packed from slot 0 (`queued`).
 // LISTS = false: a build of the caller without the units' sphere lists (ul, ul_k unused).
-template <bool LISTS>
-RT_DEV void primary_batch(const Scene& sc, const Tile& tile, const float4* __restrict__ geo0, const RtCamera& cam,
+template <bool LISTS, class SC>
+RT_DEV void primary_batch(const SC& sc, const Tile& tile, const float4* __restrict__ geo0, const RtCamera& cam,
                           const RtLaunch& L, uint64_t seed, V3 T, const Slot& u, uint32_t slot, uint32_t first,
                           uint32_t n_samp, unsigned long long* acc, float4* fold, uint32_t* q, Cand& cand,
                           const UnitList& ul, uint32_t ul_k, uint32_t& queued, uint32_t& completed, uint32_t& nseg, Stats& st) {
@@ -1506,7 +1588,7 @@ RT_DEV void render_queue_body(const Scene& sc, uint32_t* __restrict__ rgba, floa
     __syncthreads();
     // the exact-test data stays in global memory (8 KB, read a couple of times per ray, cached): with it in LDS
     // a compute unit holds four workgroups instead of five, measured 2 % slower on the 485-sphere scene
-    const Tile tile = {geo, sc.exact, L.scan_blocks ? box : nullptr, orig_of(L, sc.mat)};
+    const Tile tile = {geo, sc.exact(), L.scan_blocks ? box : nullptr, orig_of(L, sc.mat())};
 
     Stats st;
     Slot u0, u1;
@@ -1559,7 +1641,7 @@ RT_DEV void render_queue_body(const Scene& sc, uint32_t* __restrict__ rgba, floa
                         next_samp = 0u;
                         if (cur) u1 = open_unit(L, unit, n_samp); else u0 = open_unit(L, unit, n_samp);
                         if (n_samp == 0u) continue;
-                        ul_k = L.ulist_cap ? uniform_u32(unit_list(sc.geom, sc.exact, geo0, cam, L, cur ? u1.x0 : u0.x0, cur ? u1.y0 : u0.y0, ul, lane)) : RT_UL_NONE;
+                        ul_k = L.ulist_cap ? uniform_u32(unit_list(sc.geom, sc.exact(), geo0, cam, L, cur ? u1.x0 : u0.x0, cur ? u1.y0 : u0.y0, ul, lane)) : RT_UL_NONE;
                     }
                 }
             }
@@ -1821,7 +1903,7 @@ RT_DEV void render_pool_body(const Scene& sc, uint32_t* __restrict__ rgba, float
     }
     for (uint32_t i = threadIdx.x; i < 2u * L.scan_blocks; i += blockDim.x) box[i] = sc.geom[S + i];
     __syncthreads();
-    const Tile tile = {geo, sc.exact, L.scan_blocks ? box : nullptr, orig_of(L, sc.mat)};
+    const Tile tile = {geo, sc.exact(), L.scan_blocks ? box : nullptr, orig_of(L, sc.mat())};
 
     Stats st;
     bool drained = false;
@@ -1857,7 +1939,7 @@ RT_DEV void render_pool_body(const Scene& sc, uint32_t* __restrict__ rgba, float
                     band = band_of(L, x);
                     p.nb = 1u;
                 } else {
-                    const float4 al = sc.shade[2u * sphere + 1u];
+                    const float4 al = sc.shade()[2u * sphere + 1u];
                     p.thr = v3(al.x, al.y, al.z);                // 1 * albedo (ray.cu:37)
                     p.nb = 0u;
                 }
@@ -1872,7 +1954,7 @@ RT_DEV void render_pool_body(const Scene& sc, uint32_t* __restrict__ rgba, float
         if (want != 0ull && !drained) {
             uint32_t sl = 0u, first = 0u;
             uint4 head = make_uint4(0u, 0u, 0u, 0u);
-            if (pool_next_batch<LISTS>(L, slots, ctl, work, n_samp, ahead_at, lane, cam, sc.geom, sc.exact, hint, sl, first, head, drained)) {
+            if (pool_next_batch<LISTS>(L, slots, ctl, work, n_samp, ahead_at, lane, cam, sc.geom, sc.exact(), hint, sl, first, head, drained)) {
                 Slot u;
                 u.open = true; u.left = 0u;
                 u.x0 = uniform_u32(head.x);
@@ -1961,10 +2043,10 @@ RT_DEV void render_pool_body(const Scene& sc, uint32_t* __restrict__ rgba, float
 // wavefront traces its unit's next 64 between the rounds, against the unit's sphere list (unit_list) -- or, for a unit
 // with more spheres in reach than the list holds, against the launch's camera-ray terms in global memory.
 //   LDS: [geo S float4][boxes 2 x S / 32 + 2 float4], S = RT_Q_STREAM_TILE, then per wavefront as in render_queue_body.
-template <bool FOLD>
-RT_DEV void render_queue_stream_body(const Scene& sc, uint32_t* __restrict__ rgba, float4* __restrict__ linear,
+template <bool FOLD, class SC>
+RT_DEV void render_queue_stream_body(const SC& sc, uint32_t* __restrict__ rgba, float4* __restrict__ linear,
                                      unsigned long long* __restrict__ segments, uint32_t* __restrict__ work,
-                                     float4* __restrict__ fold_all, const float4* __restrict__ camterms,
+                                     float4* __restrict__ fold_all,
                                      const RtCamera& cam, const RtLaunch& L) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform: kept in a scalar register
@@ -1994,7 +2076,7 @@ RT_DEV void render_queue_stream_body(const Scene& sc, uint32_t* __restrict__ rgb
     ul.terms = reinterpret_cast<float4*>(mine + RT_Q_CAND_CAP * 128u + 48u * P + RT_Q_WORDS * 256u);
     ul.idx = reinterpret_cast<uint16_t*>(ul.terms + L.ulist_cap);
     uint32_t ul_k = RT_UL_NONE;
-    const Tile whole = {geo, sc.exact, nullptr, orig_of(L, sc.mat)};                           // exact-test data of the whole list, by sphere index
+    const Tile whole = {geo, sc.exact(), nullptr, orig_of(L, sc.mat())};                           // exact-test data of the whole list, by sphere index
     for (uint32_t k = lane; k < 6u * P; k += 64u) accum[k] = 0ull;
     float4* fold = FOLD ? fold_all + (size_t)(blockIdx.x * (blockDim.x >> 6) + wave) * (2u * P * (size_t)L.samples_per_pixel) : nullptr;
     const float4* fold1 = FOLD ? fold + (size_t)P * L.samples_per_pixel : nullptr;
@@ -2045,10 +2127,10 @@ RT_DEV void render_queue_stream_body(const Scene& sc, uint32_t* __restrict__ rgb
                 next_samp = 0u;
                 if (cur) u1 = open_unit(L, unit, n_samp); else u0 = open_unit(L, unit, n_samp);
                 if (n_samp == 0u) continue;
-                ul_k = L.ulist_cap ? uniform_u32(unit_list(sc.geom, sc.exact, camterms, cam, L, cur ? u1.x0 : u0.x0, cur ? u1.y0 : u0.y0, ul, lane)) : RT_UL_NONE;
+                ul_k = L.ulist_cap ? uniform_u32(unit_list<true>(sc.geom, sc.exact(), sc.camterms(), cam, L, cur ? u1.x0 : u0.x0, cur ? u1.y0 : u0.y0, ul, lane)) : RT_UL_NONE;
             }
             uint32_t completed = 0u;
-            primary_batch<true>(sc, whole, camterms, cam, L, seed, T, cur ? u1 : u0, cur, next_samp, n_samp, accum, fold, q, cand, ul, ul_k,
+            primary_batch<true>(sc, whole, sc.camterms(), cam, L, seed, T, cur ? u1 : u0, cur, next_samp, n_samp, accum, fold, q, cand, ul, ul_k,
                                 q_count, completed, nseg, st);
             q_head = 0u;
             next_samp = next_samp + 64u < n_samp ? next_samp + 64u : n_samp;
@@ -2105,7 +2187,7 @@ RT_DEV void render_queue_stream_body(const Scene& sc, uint32_t* __restrict__ rgb
                     else if (first / 16u + i < 2u * L.scan_blocks) box[i] = sc.geom[L.n_padded + first / 16u + i];
                 }
                 __syncthreads();
-                const Tile tile = {geo, sc.exact, box_f4 ? box : nullptr, orig_of(L, sc.mat), box_f4 ? box + (box_f4 - 2u) : nullptr};   // exact-test data: the whole list's, in global memory
+                const Tile tile = {geo, sc.exact(), box_f4 ? box : nullptr, orig_of(L, sc.mat()), box_f4 ? box + (box_f4 - 2u) : nullptr};   // exact-test data: the whole list's, in global memory
                 // every lane of a wavefront that has a ray for this tile: see scan_tile
                 if ((mine_need >> t) & 1ull)
                     scan_tile_stream(tile, count, (int)first, rterms, bt, p.o, p.d, ra, L.t_min, b, cand, st, active);
@@ -2150,7 +2232,7 @@ extern "C" __global__ void __launch_bounds__(1024)
 rt_render(const float4* geom, const float4* exact, const float4* shade, const uint32_t* mat, uint32_t* rgba,
           float4* linear, unsigned long long* segments, uint32_t* work, float4* fold, const float4* camterms,
           RtCamera cam, RtLaunch L) {
-    Scene sc = {geom, exact, shade, mat};
+    Scene sc = {geom, exact, shade, mat, camterms};
     RT_DBG_SET(segments);
     render_body<false>(sc, rgba, linear, segments, work, cam, L);
 }
@@ -2162,7 +2244,7 @@ extern "C" __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_p
 rt_render_queue(const float4* geom, const float4* exact, const float4* shade, const uint32_t* mat, uint32_t* rgba,
                 float4* linear, unsigned long long* segments, uint32_t* work, float4* fold, const float4* camterms,
                 RtCamera cam, RtLaunch L) {
-    Scene sc = {geom, exact, shade, mat};
+    Scene sc = {geom, exact, shade, mat, camterms};
     RT_DBG_SET(segments);
     render_queue_body<false, false>(sc, rgba, linear, segments, work, fold, camterms, cam, L);
 }
@@ -2173,7 +2255,7 @@ extern "C" __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_p
 rt_render_queue_boxes(const float4* geom, const float4* exact, const float4* shade, const uint32_t* mat, uint32_t* rgba,
                       float4* linear, unsigned long long* segments, uint32_t* work, float4* fold, const float4* camterms,
                       RtCamera cam, RtLaunch L) {
-    Scene sc = {geom, exact, shade, mat};
+    Scene sc = {geom, exact, shade, mat, camterms};
     RT_DBG_SET(segments);
     render_queue_body<false, true>(sc, rgba, linear, segments, work, fold, camterms, cam, L);
 }
@@ -2182,9 +2264,9 @@ extern "C" __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_p
 rt_render_queue_stream(const float4* geom, const float4* exact, const float4* shade, const uint32_t* mat, uint32_t* rgba,
                        float4* linear, unsigned long long* segments, uint32_t* work, float4* fold, const float4* camterms,
                        RtCamera cam, RtLaunch L) {
-    Scene sc = {geom, exact, shade, mat};
+    SceneAt sc = {geom, L.n_padded};                            // (the other addresses: found from this one)
     RT_DBG_SET(segments);
-    render_queue_stream_body<false>(sc, rgba, linear, segments, work, fold, camterms, cam, L);
+    render_queue_stream_body<false>(sc, rgba, linear, segments, work, fold, cam, L);
 }
 
 // rt_render_queue with the pixel units held by the workgroup (render_pool_body).
@@ -2192,7 +2274,7 @@ extern "C" __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_p
 rt_render_pool(const float4* geom, const float4* exact, const float4* shade, const uint32_t* mat, uint32_t* rgba,
                float4* linear, unsigned long long* segments, uint32_t* work, float4* fold, const float4* camterms,
                RtCamera cam, RtLaunch L) {
-    Scene sc = {geom, exact, shade, mat};
+    Scene sc = {geom, exact, shade, mat, camterms};
     RT_DBG_SET(segments);
     render_pool_body<false, true, false>(sc, rgba, linear, segments, work, nullptr, camterms, cam, L);
 }
@@ -2202,7 +2284,7 @@ extern "C" __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_p
 rt_render_pool_boxes(const float4* geom, const float4* exact, const float4* shade, const uint32_t* mat, uint32_t* rgba,
                      float4* linear, unsigned long long* segments, uint32_t* work, float4* fold, const float4* camterms,
                      RtCamera cam, RtLaunch L) {
-    Scene sc = {geom, exact, shade, mat};
+    Scene sc = {geom, exact, shade, mat, camterms};
     RT_DBG_SET(segments);
     render_pool_body<false, true, true>(sc, rgba, linear, segments, work, nullptr, camterms, cam, L);
 }
@@ -2214,7 +2296,7 @@ extern "C" __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_p
 rt_render_pool_plain(const float4* geom, const float4* exact, const float4* shade, const uint32_t* mat, uint32_t* rgba,
                      float4* linear, unsigned long long* segments, uint32_t* work, float4* fold, const float4* camterms,
                      RtCamera cam, RtLaunch L) {
-    Scene sc = {geom, exact, shade, mat};
+    Scene sc = {geom, exact, shade, mat, camterms};
     RT_DBG_SET(segments);
     render_pool_body<false, false, false>(sc, rgba, linear, segments, work, nullptr, camterms, cam, L);
 }
@@ -2226,7 +2308,7 @@ extern "C" __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_p
 rt_render_queue_fold(const float4* geom, const float4* exact, const float4* shade, const uint32_t* mat, uint32_t* rgba,
                      float4* linear, unsigned long long* segments, uint32_t* work, float4* fold, const float4* camterms,
                      RtCamera cam, RtLaunch L) {
-    Scene sc = {geom, exact, shade, mat};
+    Scene sc = {geom, exact, shade, mat, camterms};
     RT_DBG_SET(segments);
     render_queue_body<true, true>(sc, rgba, linear, segments, work, fold, camterms, cam, L);
 }
@@ -2236,7 +2318,7 @@ extern "C" __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_p
 rt_render_pool_fold(const float4* geom, const float4* exact, const float4* shade, const uint32_t* mat, uint32_t* rgba,
                     float4* linear, unsigned long long* segments, uint32_t* work, float4* fold, const float4* camterms,
                     RtCamera cam, RtLaunch L) {
-    Scene sc = {geom, exact, shade, mat};
+    Scene sc = {geom, exact, shade, mat, camterms};
     RT_DBG_SET(segments);
     render_pool_body<true, true, true>(sc, rgba, linear, segments, work, fold, camterms, cam, L);
 }
@@ -2245,16 +2327,16 @@ extern "C" __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_p
 rt_render_queue_stream_fold(const float4* geom, const float4* exact, const float4* shade, const uint32_t* mat, uint32_t* rgba,
                             float4* linear, unsigned long long* segments, uint32_t* work, float4* fold, const float4* camterms,
                             RtCamera cam, RtLaunch L) {
-    Scene sc = {geom, exact, shade, mat};
+    SceneAt sc = {geom, L.n_padded};                            // (the other addresses: found from this one)
     RT_DBG_SET(segments);
-    render_queue_stream_body<true>(sc, rgba, linear, segments, work, fold, camterms, cam, L);
+    render_queue_stream_body<true>(sc, rgba, linear, segments, work, fold, cam, L);
 }
 
 extern "C" __global__ void __launch_bounds__(1024)
 rt_render_stream(const float4* geom, const float4* exact, const float4* shade, const uint32_t* mat, uint32_t* rgba,
                  float4* linear, unsigned long long* segments, uint32_t* work, float4* fold, const float4* camterms,
                  RtCamera cam, RtLaunch L) {
-    Scene sc = {geom, exact, shade, mat};
+    Scene sc = {geom, exact, shade, mat, camterms};
     RT_DBG_SET(segments);
     render_body<true>(sc, rgba, linear, segments, work, cam, L);
 }

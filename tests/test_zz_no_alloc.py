@@ -130,7 +130,7 @@ COUNTING_WORKER = textwrap.dedent("""
 
     with rt.HipWorld(0, rt.scene_book1_final(1)) as hip:
         after_setup = counts()
-        assert after_setup[0] >= 5, after_setup                # rt_upload_scene's buffers went through the counter
+        assert after_setup[0] >= 1, after_setup                # rt_upload_scene's allocation went through the counter
         big = rt.Camera.look_at(16.0 / 9.0, 200, 20.0, (13.0, 2.0, 3.0), (0.0, 0.0, 0.0))
         small = rt.Camera.look_at(16.0 / 9.0, 72, 20.0, (13.0, 2.0, 3.0), (0.0, 0.0, 0.0))
         d_rgba, d_lin = dmalloc(112 * 200 * 4), dmalloc(112 * 200 * 16)
