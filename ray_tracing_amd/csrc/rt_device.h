@@ -56,7 +56,8 @@ typedef struct RtLaunch {
 #ifndef RT_SCAN_UNROLL
 #define RT_SCAN_UNROLL 8u
 #endif
-// ... and in the builds with block boxes, where the dense scan is the lesser part and registers are short
+// ... and in the builds with block boxes, where the dense scan is the lesser part and registers are short (8 there:
+// 12 to 56 more bytes of scratch per lane, book frame 311 -> 326 ms, mirror hall 331 -> 350, 16,385 spheres 70.5 -> 74)
 #ifndef RT_SCAN_UNROLL_BOXES
 #define RT_SCAN_UNROLL_BOXES 4u
 #endif
