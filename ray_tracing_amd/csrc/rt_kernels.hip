@@ -834,23 +834,24 @@ RT_DEV uint32_t unit_list(const float4* __restrict__ geom, const float4* __restr
                           const RtLaunch& L, uint32_t x0, uint32_t y0, const UnitList& ul, uint32_t lane) {
     float ux, uy, uz, opx, opy, opz, s;
     {
-        // (the launch's constants pass through an empty volatile asm: otherwise the parts of the sums below that do not
-        // depend on the unit are computed once, before the render loop, and five doubles sit in every lane's scratch)
+        // (the launch's constants pass through an empty volatile asm: otherwise everything below that does not depend on
+        // the unit -- the conversions to double, half the unit's size, pixel00 - o -- is computed once, before the render
+        // loop, and a dozen doubles sit in registers and in every lane's scratch through the loop)
+        auto fresh = [](float v) { asm volatile("" : "+s"(v)); return (double)v; };
         uint32_t unit_w = L.unit_w, unit_h = L.unit_h;
-        float cx = cam.center[0], cy = cam.center[1], cz = cam.center[2];
-        asm volatile("" : "+s"(unit_w), "+s"(unit_h), "+s"(cx), "+s"(cy), "+s"(cz));
+        asm volatile("" : "+s"(unit_w), "+s"(unit_h));
         const double fxc = (double)x0 + 0.5 * ((double)unit_w - 0.5), fyc = (double)y0 + 0.5 * ((double)unit_h - 0.5);
-        const double ox = cx, oy = cy, oz = cz;
-        const double dx = ((double)cam.pixel00_loc[0] - ox) + (fxc * (double)cam.pixel_delta_u[0] + fyc * (double)cam.pixel_delta_v[0]);
-        const double dy = ((double)cam.pixel00_loc[1] - oy) + (fxc * (double)cam.pixel_delta_u[1] + fyc * (double)cam.pixel_delta_v[1]);
-        const double dz = ((double)cam.pixel00_loc[2] - oz) + (fxc * (double)cam.pixel_delta_u[2] + fyc * (double)cam.pixel_delta_v[2]);
+        const double ox = fresh(cam.center[0]), oy = fresh(cam.center[1]), oz = fresh(cam.center[2]);
+        const double dx = (fresh(cam.pixel00_loc[0]) - ox) + (fxc * fresh(cam.pixel_delta_u[0]) + fyc * fresh(cam.pixel_delta_v[0]));
+        const double dy = (fresh(cam.pixel00_loc[1]) - oy) + (fxc * fresh(cam.pixel_delta_u[1]) + fyc * fresh(cam.pixel_delta_v[1]));
+        const double dz = (fresh(cam.pixel00_loc[2]) - oz) + (fxc * fresh(cam.pixel_delta_u[2]) + fyc * fresh(cam.pixel_delta_v[2]));
         const double len2 = dx * dx + dy * dy + dz * dz;
         const float len_lo = __builtin_amdgcn_sqrtf((float)len2) * (1.0f - 0x1p-20f);
         if (!(len_lo > L.unit_reach)) return RT_UL_NONE;          // wave-uniform: every operand is
         s = L.unit_reach / len_lo * (1.0f + 0x1p-20f) + 0x1p-18f;
         const double inv = 1.0 / sqrt(len2);
         ux = (float)(dx * inv); uy = (float)(dy * inv); uz = (float)(dz * inv);
-        opx = (float)(ox - (double)L.translate[0]); opy = (float)(oy - (double)L.translate[1]); opz = (float)(oz - (double)L.translate[2]);
+        opx = (float)(ox - fresh(L.translate[0])); opy = (float)(oy - fresh(L.translate[1])); opz = (float)(oz - fresh(L.translate[2]));
     }
     const UnitBundle ub = {ux, uy, uz, opx, opy, opz, s};
     return unit_list_scan<BLOCKS>(geom, exact, terms, ul.terms, ul.idx, ub, L.n_padded, L.scan_blocks, L.ulist_cap, lane);
