@@ -398,6 +398,13 @@ def test_camera_ray_scan_with_hostile_cameras(oracle, rt, hip):
         ("far from the origin", scene(40, (1.0e4, -2.0e3, 5.0e3)), (1.0e4 + 9.0, -2.0e3 + 2.0, 5.0e3 + 6.0),
          (1.0e4, -2.0e3 + 0.5, 5.0e3), 40.0),
         ("streamed list", scene(1100), (9.0, 3.0, 7.0), (0.0, 0.5, 0.0), 45.0),
+        # ... whose pixel units test the ball round a block of 32 spheres before the block's spheres
+        ("streamed list, inside the glass sphere", scene(1100), (0.1, 1.2, -0.2), (3.0, 0.5, 1.0), 60.0),
+        ("streamed list, among the spheres, wide", scene(1100), (2.0, 2.0, 2.0), (0.0, 0.5, 0.0), 150.0),
+        ("streamed list, just above the ground", scene(1100), (4.0, 1e-3, 4.0), (0.0, 0.5, 0.0), 50.0),
+        ("streamed list, narrow", scene(1100), (20.0, 3.0, 15.0), (0.0, 1.0, 0.0), 1.5),
+        ("streamed list, far from the origin", scene(1100, (1.0e4, -2.0e3, 5.0e3)), (1.0e4 + 9.0, -2.0e3 + 2.0, 5.0e3 + 6.0),
+         (1.0e4, -2.0e3 + 0.5, 5.0e3), 40.0),
     ]
     for name, sp, lookfrom, lookat, vfov in cases:
         cam = rt.Camera.look_at(16.0 / 9.0, 96, vfov, lookfrom, lookat)
@@ -542,8 +549,8 @@ def test_device_list_layouts_at_their_edges(oracle, rt, hip):
 
 
 def test_list_of_more_than_64_tiles(oracle, rt, hip):
-    """40,001 spheres: 79 tiles of 512.  The workgroup's vote covers the first 64 tiles of a round; the tiles beyond
-    are staged for everybody and every lane with a ray tests the boxes of their blocks.  Chunked and fold order against
+    """40,001 spheres: 157 tiles of 256, voted on in groups of 64 tiles; 1,251 blocks of 32, whose balls the pixel
+    units' lists test 64 at a time.  Chunked and fold order against
     the checker, bit for bit (a small frame: the checker tests every sphere for every segment)."""
     sp = rt.scene_grid(5, 200)
     assert len(sp) > 64 * 512

@@ -352,12 +352,8 @@ def unit_reach(cam, uw, uh):
     return np.nextafter(f32(reach), f32(np.inf))
 
 
-def unit_listed(cam, x0, y0, uw, uh, c, rr, T=(0.0, 0.0, 0.0)):
-    """unit_list of the kernel for the unit at (x0, y0) (arrays: one unit and one sphere per element), operation for
-    operation: the unit's central direction u, o' = o - T and s in double precision, rounded to single; per sphere in
-    single precision q = c' - o' (c' = c - T as uploaded), the distance to the central line as |q x u|, and
-    bound = r_eff + |q| s + 2^-20 (|o'| + |c'|).  The hardware's 1-ulp square roots are modelled 2 ulps too SMALL where
-    a larger value lists more, too large where it lists less (the model is then stricter than the kernel)."""
+def unit_bundle(cam, x0, y0, uw, uh, T=(0.0, 0.0, 0.0)):
+    """The per-unit part of unit_list: central direction u, o' = o - T, the bundle's sine s and 2^-20 |o'| (1-norm)."""
     o, p00, du, dv, W, H = [x.astype(np.float64) if isinstance(x, np.ndarray) else x for x in _cam_arrays(cam)]
     T = np.array(T, dtype=f32)
     reach = unit_reach(cam, uw, uh)
@@ -374,6 +370,18 @@ def unit_listed(cam, x0, y0, uw, uh, c, rr, T=(0.0, 0.0, 0.0)):
     u = [(d[k] * inv).astype(f32) for k in range(3)]
     op = [np.full_like(u[0], f32(o[k] - np.float64(T[k]))) for k in range(3)]
     o_abs = (f32(2.0 ** -20) * ((np.abs(op[0]) + np.abs(op[1])).astype(f32) + np.abs(op[2])).astype(f32)).astype(f32)
+    return u, op, s_, o_abs
+
+
+def unit_listed(cam, x0, y0, uw, uh, c, rr, T=(0.0, 0.0, 0.0)):
+    """unit_list of the kernel for the unit at (x0, y0) (arrays: one unit and one sphere per element), operation for
+    operation: the unit's central direction u, o' = o - T and s in double precision, rounded to single; per sphere in
+    single precision q = c' - o' (c' = c - T as uploaded), the distance to the central line as |q x u|, and
+    bound = r_eff + |q| s + 2^-20 (|o'| + |c'|).  The hardware's 1-ulp square roots are modelled 2 ulps too SMALL where
+    a larger value lists more, too large where it lists less (the model is then stricter than the kernel)."""
+    u, op, s_, o_abs = unit_bundle(cam, x0, y0, uw, uh, T)
+    T = np.array(T, dtype=f32)
+    down = lambda x: np.nextafter(np.nextafter(x, f32(0.0)), f32(0.0))
     cp = [(c[k].astype(np.float64) - np.float64(T[k])).astype(f32) for k in range(3)]           # upload, in double
     q = [(cp[k] - op[k]).astype(f32) for k in range(3)]
     qq = (fma(q[2], q[2], fma(q[1], q[1], (q[0] * q[0]).astype(f32))) * f32(1.0 + 2.0 ** -20)).astype(f32)
@@ -447,7 +455,6 @@ def test_unit_lists_hold_every_sphere_a_ray_of_the_unit_can_hit():
                         assert listed[clear].mean() < 0.01, (label, listed[clear].mean())
 
 
-# ---------------------------------------------------------------- block boxes (rt_upload_scene, scan_tile)
 def block_box(cp, r, R):
     """rt_upload_scene: the box of a block of spheres (arrays [members, blocks]) in coordinates relative to T: every
     sphere's own |r| (1 + 2^-10) + 2^-9 |c'| + 2^-19 R beyond its centre, rounded outwards."""
@@ -457,6 +464,86 @@ def block_box(cp, r, R):
     hi = [np.nextafter((cp[k].astype(np.float64) + ext).astype(f32), f32(np.inf)).max(axis=0) for k in range(3)]
     return lo, hi
 
+def block_ball(lo, hi):
+    """rt_upload_scene: the ball round a block's box -- centre rounded to single precision, radius half the diagonal
+    plus the centre's rounding, times 1 + 2^-7, rounded up."""
+    mid = [0.5 * (lo[k].astype(np.float64) + hi[k].astype(np.float64)) for k in range(3)]
+    d2 = sum((hi[k].astype(np.float64) - lo[k].astype(np.float64)) ** 2 for k in range(3))
+    c1 = sum(np.abs(m) for m in mid)
+    rb = (0.5 * np.sqrt(d2) * (1.0 + 2.0 ** -40) + 2.0 ** -22 * c1) * (1.0 + 2.0 ** -7)
+    return [m.astype(f32) for m in mid], np.nextafter(rb.astype(f32), f32(np.inf))
+
+
+def ball_reached(cam, x0, y0, uw, uh, cb, rb, T=(0.0, 0.0, 0.0)):
+    """unit_list's test of a block's ball, operation for operation (square roots 2 ulps too small: stricter than the kernel)."""
+    u, op, s_, o_abs = unit_bundle(cam, x0, y0, uw, uh, T)
+    down = lambda x: np.nextafter(np.nextafter(x, f32(0.0)), f32(0.0))
+    q = [(cb[k] - op[k]).astype(f32) for k in range(3)]
+    q_len = (down(np.sqrt(fma(q[2], q[2], fma(q[1], q[1], (q[0] * q[0]).astype(f32))))) * f32(1.0 + 2.0 ** -18)).astype(f32)
+    t = fma(u[2], q[2], fma(u[1], q[1], (u[0] * q[0]).astype(f32)))
+    kx = fma(q[1], u[2], -(q[2] * u[1]).astype(f32))
+    ky = fma(q[2], u[0], -(q[0] * u[2]).astype(f32))
+    kz = fma(q[0], u[1], -(q[1] * u[0]).astype(f32))
+    dist2 = fma(kz, kz, fma(ky, ky, (kx * kx).astype(f32)))
+    c_abs = ((np.abs(cb[0]) + np.abs(cb[1])).astype(f32) + np.abs(cb[2])).astype(f32)
+    first = fma((q_len + rb).astype(f32), (s_.astype(f32) + f32(2.0 ** -8)).astype(f32), rb)
+    bound = ((first + fma(np.full_like(c_abs, f32(2.0 ** -19)), c_abs, (f32(2.0) * o_abs).astype(f32))).astype(f32) * f32(1.0 + 2.0 ** -18)).astype(f32)
+    return ~(dist2 > (bound * bound).astype(f32)) & ~(t < -bound)
+
+
+def test_unit_lists_of_streamed_scenes_reach_the_block_of_every_listed_sphere():
+    """A streamed scene's unit lists look at a block's spheres only if the ball round the block's box passes: for every
+    sphere the sphere test lists (grazing, squarely hit, camera inside, behind), in blocks of neighbours from a tenth to
+    ten times its size around it, the block's ball passes too; and balls far off the unit's line do not."""
+    rng = np.random.default_rng(10)
+    n, members = 100_000, 6
+    for name, cam in _cameras().items():
+        o_, p00, du, dv, W, H = _cam_arrays(cam)
+        for uw, uh in ((8, 2), (4, 1), (16, 1)):
+            x0 = (rng.integers(0, max(1, W // uw), n) * uw).astype(np.int64)
+            y0 = (rng.integers(0, max(1, H // uh), n) * uh).astype(np.int64)
+            fx = (x0 + rng.uniform(-0.5, uw, n)).astype(f32)
+            fy = (y0 + rng.uniform(-0.5, uh, n)).astype(f32)
+            o, d = camera_ray(cam, fx, fy)
+            d64 = np.stack([x.astype(np.float64) for x in d])
+            u = d64 / np.linalg.norm(d64, axis=0)
+            perp = np.cross(u.T, unit(rng, n).T).T
+            perp /= np.linalg.norm(perp, axis=0)
+            scale = max(1.0, float(np.linalg.norm(p00.astype(np.float64) - o_.astype(np.float64))))
+            r = rng.uniform(0.05, 2.0, n) * rng.choice([1.0, 1.0, 30.0], n)
+            dist = rng.uniform(0.2, 80.0, n) * scale * rng.choice([1.0, -1.0], n, p=[0.9, 0.1])
+            miss = np.where(rng.random(n) < 0.5, 1.0 + rng.uniform(-4e-7, 4e-7, n), rng.uniform(0.0, 6.0, n))
+            c0 = o_.astype(np.float64)[:, None] + u * dist + perp * r * miss
+            inside = rng.random(n) < 0.1                                   # the camera inside the sphere
+            c0 = np.where(inside, o_.astype(np.float64)[:, None] + unit(rng, n) * r * rng.uniform(0.0, 1.0, n), c0)
+            spread = r * np.exp(rng.uniform(np.log(0.1), np.log(10.0), n))
+            for T in ((0.0, 0.0, 0.0), tuple(np.median(c0, axis=1)), tuple(o_.astype(np.float64) + 1000.0 * scale)):
+                # the block: the sphere and its neighbours, [members, n] per axis, as uploaded (relative to T)
+                cs = [np.stack([c0[k]] + [c0[k] + spread * rng.uniform(-1.0, 1.0, n) for _ in range(members - 1)]) for k in range(3)]
+                rs = np.stack([r] + [r * rng.uniform(0.2, 1.5, n) for _ in range(members - 1)]).astype(f32)
+                c32 = [x.astype(f32) for x in cs]
+                cp = [(c32[k].astype(np.float64) - np.float64(f32(T[k]))).astype(f32) for k in range(3)]
+                R = float(max(np.abs(np.stack(cp)).max() * 2.0, 1.0))
+                lo, hi = block_box(cp, rs, R)
+                cb, rb = block_ball(lo, hi)
+                reached = ball_reached(cam, x0, y0, uw, uh, cb, rb, T=T)
+                label = f"{name}, {uw}x{uh} units, T = {T}"
+                some = 0
+                for m in range(members):
+                    listed = unit_listed(cam, x0, y0, uw, uh, [c32[k][m] for k in range(3)], (rs[m] * rs[m]).astype(f32), T=T)
+                    some += int(listed.sum())
+                    lost = listed & ~reached
+                    assert not lost.any(), f"{label}: {lost.sum()} listed spheres in blocks whose ball does not pass"
+                assert some > 1000, label
+                if T == (0.0, 0.0, 0.0) and "far" not in name:
+                    far_off = (miss > 4.5) & ~inside     # (the ball: sqrt 3 x 1.7 r)
+                    far_off = far_off & (dist > 0) & (spread < 0.2 * r) & (r > 2.0 ** -5 * np.abs(dist)) & \
+                              (r > 8.0 * np.abs(dist) * float(unit_reach(cam, uw, uh)) / np.linalg.norm(d64, axis=0))
+                    if far_off.sum() > 100:
+                        assert reached[far_off].mean() < 0.05, (label, reached[far_off].mean())
+
+
+# ---------------------------------------------------------------- block boxes (rt_upload_scene, scan_tile)
 
 def box_reached(lo, hi, op, d, rcp_ulp=0, sigma=1.0):
     """scan_tile's slab test, operation for operation: the box grown by 2^-9 |o'| (1 + 2^-8) for this ray; a plane's
