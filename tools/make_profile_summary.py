@@ -8,12 +8,12 @@ dst = os.path.join(root, "profiles")
 os.makedirs(dst, exist_ok=True)
 
 # 1. kernel-trace --stats summary (verbatim rows, long torch kernel names shortened)
-stats = glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)[0]
+stats = max(glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)
 with open(stats) as f, open(os.path.join(dst, f"{tag}_kernel_stats.csv"), "w") as g:
     for row in csv.reader(f):
         row[0] = row[0][:80]
         g.write(",".join(f'"{c}"' for c in row) + "\n")
-trace = glob.glob(os.path.join(src, "trace", "**", "*kernel_trace.csv"), recursive=True)[0]
+trace = max(glob.glob(os.path.join(src, "trace", "**", "*kernel_trace.csv"), recursive=True), key=os.path.getmtime)
 bench_line = [l for l in open(os.path.join(src, "trace.log")) if l.startswith("{")][-1]
 bench = json.loads(bench_line)
 KERNEL = bench["roofline"]["kernel"]
@@ -22,7 +22,13 @@ durs = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in csv
 # 2. PMC passes
 pmc = collections.defaultdict(float)
 meta = {}
+# (one file per pass: a directory that has collected the files of several runs contributes its newest only)
+newest = {}
 for f in glob.glob(os.path.join(src, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
+    d = os.path.relpath(f, src).split(os.sep)[0]
+    if d not in newest or os.path.getmtime(f) > os.path.getmtime(newest[d]):
+        newest[d] = f
+for f in sorted(newest.values()):
     per = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         if r["Kernel_Name"] != KERNEL:

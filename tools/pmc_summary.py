@@ -3,6 +3,8 @@ import collections, csv, glob, os, sys
 path = sys.argv[1]
 want = sys.argv[2] if len(sys.argv) > 2 else "rt_"
 files = [path] if path.endswith(".csv") else glob.glob(os.path.join(path, "**", "*counter_collection.csv"), recursive=True)
+if len(files) > 1:                                   # a directory that has collected several runs: the newest only
+    files = [max(files, key=os.path.getmtime)]
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 disp = collections.defaultdict(set)
 meta = {}
