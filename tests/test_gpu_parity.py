@@ -546,6 +546,17 @@ def test_device_list_layouts_at_their_edges(oracle, rt, hip):
         sp = scene(n_small, n_large)
         check_render(oracle, hip, cam, sp, rt.DeviceGUI(samples_per_pixel=6, max_depth=12, seed=5, sample_chunk=1))
         check_render(oracle, hip, cam, sp, rt.DeviceGUI(samples_per_pixel=5, max_depth=12, seed=6))
+    # Streamed lists.  The scene's arrays are one allocation, and the streaming kernels find exact-test data, shading
+    # data, camera-ray terms and material tags behind the filter data, its blocks' and tiles' boxes and its blocks'
+    # balls from the sphere count alone: counts just beyond one LDS tile, at and round whole 256-sphere tiles, with
+    # large spheres set apart (a count that is no multiple of 32) and without.
+    small_cam = rt.Camera.look_at(1.5, 64, 60.0, (14.0, 6.0, 16.0), (0.0, 0.0, 0.0))
+    for n_small, n_large in ((1025, 0), (1026, 3), (1279, 0), (1280, 0), (1281, 1), (1535, 30), (2049, 0)):
+        sp = scene(n_small, n_large)
+        check_render(oracle, hip, small_cam, sp, rt.DeviceGUI(samples_per_pixel=4, max_depth=10, seed=7, sample_chunk=1))
+        assert hip.last_kernel_name() == "rt_render_queue_stream", (n_small, n_large)
+        check_render(oracle, hip, small_cam, sp, rt.DeviceGUI(samples_per_pixel=3, max_depth=10, seed=8))
+        assert hip.last_kernel_name() == "rt_render_queue_stream_fold", (n_small, n_large)
 
 
 def test_list_of_more_than_64_tiles(oracle, rt, hip):
