@@ -48,7 +48,10 @@ const char *rt_last_error(const rt_ctx *ctx);
 
 /* Replaces the kernels by another gfx950 code object image (hipModuleLoadData), or reloads the
  * embedded one when image == NULL.  Stands for CudaWorld::compile_ptx (ray_tracing.rs:129-161);
- * the reference compiles at run time with NVRTC, here the object is built by hipcc --genco. */
+ * the reference compiles at run time with NVRTC, here the object is built by hipcc --genco.
+ * The object must come from this library's rt_kernels.hip with this library's tile size of the streaming
+ * kernels (its word rt_stream_tile is checked: the scene's layout in device memory follows from it); any
+ * other is refused with RT_ERR_INVALID and the context keeps the module it had. */
 int rt_load_module(rt_ctx *ctx, const void *image, size_t size);
 
 /* Uploads the sphere list: AoS host spheres -> device arrays (scan-filter data, exact {c, r*r},

@@ -151,6 +151,26 @@ int load_image(rt_ctx* c, const void* image) {
             (void)hipGetLastError();
         }
     }
+    // the tile size of the object's streaming kernels: rt_upload_scene lays the scene out for RT_Q_STREAM_TILE, and those
+    // kernels find the arrays from it (objects without the word: built before the layout depended on it -- refused too)
+    {
+        hipDeviceptr_t sym = nullptr;
+        size_t sym_bytes = 0;
+        uint32_t word = 0;
+        if (hipModuleGetGlobal(&sym, &sym_bytes, m, "rt_stream_tile") != hipSuccess || !sym || sym_bytes != sizeof word) {
+            (void)hipGetLastError();
+            (void)hipModuleUnload(m);
+            return fail(c, RT_ERR_INVALID, "code object does not state the tile size of its streaming kernels (rt_stream_tile)");
+        }
+        if ((e = hipMemcpy(&word, sym, sizeof word, hipMemcpyDeviceToHost)) != hipSuccess) {
+            (void)hipModuleUnload(m);
+            return hip_fail(c, e, "hipMemcpy(rt_stream_tile)");
+        }
+        if (word != RT_Q_STREAM_TILE) {
+            (void)hipModuleUnload(m);
+            return fail(c, RT_ERR_INVALID, "code object was built for " + std::to_string(word) + "-sphere tiles, this library for " + std::to_string(RT_Q_STREAM_TILE));
+        }
+    }
     if (need > c->cap_counter) {
         void* fresh = nullptr;
         if ((e = hipMalloc(&fresh, need)) != hipSuccess) { (void)hipModuleUnload(m); return hip_fail(c, e, "hipMalloc(counter block)"); }

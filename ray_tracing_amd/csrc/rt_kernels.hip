@@ -28,6 +28,9 @@
 
 // size of the launch-wide counter block these kernels were built for (read by the launcher when the object is loaded)
 extern "C" __device__ __attribute__((used)) const uint32_t rt_counter_bytes = RT_COUNTER_BYTES;
+// ... and the tile size of its streaming kernels: the scene's layout in device memory follows from it (SceneAt), so the
+// launcher refuses an object built for another one.
+extern "C" __device__ __attribute__((used)) const uint32_t rt_stream_tile = RT_Q_STREAM_TILE;
 
 struct V3 { float x, y, z; };
 RT_DEV V3 v3(float x, float y, float z) { V3 v; v.x = x; v.y = y; v.z = z; return v; }

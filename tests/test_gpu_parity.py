@@ -1057,6 +1057,12 @@ def test_module_reload(rt, hip):
     assert hip.render(cam, rt.DeviceGUI())["rays"] > 0
     with pytest.raises(rt.RtError):
         hip.load_module(b"\x00" * 128)
+    # an object built for another tile size of the streaming kernels (the scene's layout in device memory follows from
+    # it) is refused, and the context keeps the module it had
+    other = os.path.join(os.path.dirname(rt.__file__), "csrc", "rt_kernels_x_tile128.hsaco")
+    with pytest.raises(rt.RtError, match="128-sphere tiles"):
+        hip.load_module(open(other, "rb").read())
+    assert hip.render(cam, rt.DeviceGUI())["rays"] > 0
 
 
 def test_command_line_renderer_writes_the_same_frame(oracle, rt, tmp_path):
