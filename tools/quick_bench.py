@@ -22,6 +22,8 @@ w = rt.HipWorld(0, sp)
 # scheduling experiments, from the environment of the A/B scripts: RT_UNIT=WxH, RT_NO_QUEUE=1, RT_SCHED=wave|pool
 _u = os.environ.get("RT_UNIT")
 w.debug_schedule(unit=tuple(int(v) for v in _u.split("x")) if _u else None, no_queue=os.environ.get("RT_NO_QUEUE") == "1", scheduler=os.environ.get("RT_SCHED", "auto"))
+if os.environ.get("RT_BRUTE") == "1":                      # every segment against every sphere (rt_debug_cull)
+    w.debug_cull(unit_lists=False, block_boxes=False)
 hs = os.environ.get("RT_HSACO")
 if hs:
     w.load_module(open(hs, "rb").read())
