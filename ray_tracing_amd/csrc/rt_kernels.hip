@@ -434,7 +434,11 @@ RT_DEV V3 filter_dir(V3 d, float a, float sigma) {
 
 // the filter's per-ray constants (scan_tile); op = o - T
 RT_DEV RayTerms ray_terms(V3 op, V3 d, float a, float sigma) {
-    const float s2 = sigma * sigma;
+    // (sigma, a launch constant in a scalar register, passes through an empty volatile asm: its square and twice its
+    // square are then two instructions here instead of two vector registers held through the render loop)
+    float sg = sigma;
+    asm volatile("" : "+s"(sg));
+    const float s2 = sg * sg;
     RayTerms r;
     r.uf = filter_dir(d, a, sigma);
     r.e = -vdot(r.uf, op);
@@ -1091,7 +1095,12 @@ RT_DEV long long to_fixed(float x) {
     uint32_t lo = (uint32_t)(frac * 4294967296.0f);              // truncation
     return (long long)(int)hi * 4294967296ll + (long long)lo;
 }
-RT_DEV float fixed_mean(long long sum, uint32_t spp) { return (float)((double)sum * 0x1p-32 / (double)spp); }
+// (spp, wave-uniform, passes through an empty volatile asm: its conversion to double is then made here, at a unit's
+// write-out, instead of once ahead of the render loop and kept in two vector registers through it)
+RT_DEV float fixed_mean(long long sum, uint32_t spp) {
+    asm volatile("" : "+s"(spp));
+    return (float)((double)sum * 0x1p-32 / (double)spp);
+}
 
 // Work distribution.  The frame (or this launch's rows of it) is cut into units of unit_w x unit_h pixels
 // (8x8, 8x1, ...); a unit's samples are cut into work items of `chunk` consecutive samples of one
