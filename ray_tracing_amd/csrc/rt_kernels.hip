@@ -410,6 +410,7 @@ RT_DEV uint32_t sparse_block(const RayTerms& r, const float4* geo_blk, unsigned 
 struct BoxTerms { V3 inv, n_lo, n_hi; };
 RT_DEV BoxTerms box_terms(V3 op, V3 uf, float sigma) {
     BoxTerms bt;
+    asm volatile("" : "+s"(sigma));                               // (made here, per ray, rather than kept through the render loop)
     const float lim = 0x1p40f * __builtin_amdgcn_rcpf(sigma);
     bt.inv = v3(__builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(uf.x), -lim, lim), __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(uf.y), -lim, lim),
                 __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(uf.z), -lim, lim));
