@@ -974,9 +974,10 @@ int rt_upload_scene(rt_ctx* c, const RtSphere* spheres, uint32_t n) {
     // One allocation, the arrays at offsets that follow from n_padded alone (SceneAt in rt_kernels.hip finds them from
     // the first address): filter data with the boxes and balls, exact-test data, shading data (3 float4 per sphere),
     // the launch's camera-ray terms, then the material tags and the caller's index of each device sphere.
-    if (c->d_geom) { RT_HIP(c, hipFree(c->d_geom)); }
+    void* old_scene = c->d_geom;
     c->d_geom = c->d_exact = c->d_shade = c->d_mat = c->d_camterms = nullptr;
     c->have_scene = false;
+    if (old_scene) { RT_HIP(c, hipFree(old_scene)); }
     RT_HIP(c, hipMalloc(&c->d_geom, geom_bytes + 5 * bytes + (size_t)n_padded * 8u));
     c->d_exact = (char*)c->d_geom + geom_bytes;
     c->d_shade = (char*)c->d_exact + bytes;
